@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""make_golden.py -- TEST INFRASTRUCTURE: generate tests/golden/*.npz from the reference itself.
+
+Runs oracle/_ref/ref_harness (the unmodified reference hot path built by oracle/ref/Makefile, driven by
+this repo's ref_harness.F90) in the build container and stores its outputs as small numpy fixtures.
+Only data is written (inputs and expected outputs); no reference source travels.
+
+    python oracle/ref/make_golden.py            # ne2 fixtures (seconds)
+    python oracle/ref/make_golden.py --long     # + ne8 12-day DCMIP 1-1 / 1-day 1-2 norms (minutes, 6 ranks)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle as po  # noqa: E402
+import norms  # noqa: E402
+
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+VCOORD = "/root/reference/test/vcoord"
+GOLD = os.path.join(ROOT, "tests", "golden")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def run(ne, qsize, nsteps, tstep, nu_q, test, dumpfreq, nranks=1, outdir=None):
+    outdir = outdir or tempfile.mkdtemp(prefix="tse_ref_")
+    os.makedirs(outdir, exist_ok=True)
+    stdin = "%d %d %d %r %r %d %d\n'%s'\n'%s'\n" % (ne, qsize, nsteps, tstep, nu_q, test, dumpfreq, outdir, VCOORD)
+    res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS], input=stdin.encode(), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, check=True)
+    return outdir, res.stdout.decode()
+
+
+def make_ne2():
+    cfg = dict(ne=2, qsize=5, nsteps=6, tstep=1800.0, nu_q=1e19, test=1)
+    outdir, log = run(dumpfreq=1, **cfg)
+    st = po.read_static(os.path.join(outdir, "static_000000_r0000.bin"))
+    ops, remaps = po.read_ops(os.path.join(outdir, "ops_000000_r0000.bin"))
+    np.savez_compressed(os.path.join(GOLD, "ref_ne2_static.npz"), **{k: v for k, v in st.items()})
+    np.savez_compressed(
+        os.path.join(GOLD, "ref_ops.npz"),
+        ie=np.array([o["ie"] for o in ops]), s=np.array([o["s"] for o in ops]), v=np.array([o["v"] for o in ops]),
+        div=np.array([o["div"] for o in ops]), grad=np.array([o["grad"] for o in ops]),
+        div_wk=np.array([o["div_wk"] for o in ops]), lap_wk=np.array([o["lap_wk"] for o in ops]),
+        remap_dp1=np.array([r["dp1"] for r in remaps]), remap_dp2=np.array([r["dp2"] for r in remaps]),
+        remap_Qin=np.array([r["Qin"] for r in remaps]), remap_Qout=np.array([r["Qout"] for r in remaps]))
+    s1 = po.read_state(os.path.join(outdir, "state_000001_r0000.bin"))
+    s3 = po.read_state(os.path.join(outdir, "state_000003_r0000.bin"))
+    s6 = po.read_state(os.path.join(outdir, "state_000006_r0000.bin"))
+    sub = np.array([0, 3, 5, 10, 17, 23])  # elements whose step-1 derived fields are kept
+    np.savez_compressed(
+        os.path.join(GOLD, "ref_ne2_dcmip11.npz"), config=json.dumps(cfg),
+        qdp_step1=s1["qdp"], qdp_step3=s3["qdp"], qdp_step6=s6["qdp"],
+        sub=sub, vn0_step1=s1["vn0"][sub], dp_step1=s1["dp"][sub], divdp_step1=s1["divdp"][sub],
+        divdp_proj_step1=s1["divdp_proj"][sub], eta_dot_dpdn_step1=s1["eta_dot_dpdn"][sub],
+        dp3d_step3=s3["dp3d"], ps_v_step3=s3["ps_v"])
+    # DCMIP 1-2
+    cfg2 = dict(ne=2, qsize=3, nsteps=3, tstep=600.0, nu_q=1e19, test=2)
+    outdir2, _ = run(dumpfreq=0, **cfg2)
+    t3 = po.read_state(os.path.join(outdir2, "state_000003_r0000.bin"))
+    np.savez_compressed(os.path.join(GOLD, "ref_ne2_dcmip12.npz"), config=json.dumps(cfg2), qdp_step3=t3["qdp"])
+    # the reference on 2 ranks: its own bit-for-bit check + a multi-rank schedule (putmap/getmap with
+    # neighbour-rank slots) for the host-side descriptor conversion tests
+    outdir3, _ = run(dumpfreq=0, nranks=2, **cfg)
+    sts = [po.read_static(os.path.join(outdir3, "static_000000_r%04d.bin" % r)) for r in range(2)]
+    g6 = gather_state_with_gid(outdir3, "000006", 2, sts)
+    bfb = bool(np.array_equal(g6["qdp"], s6["qdp"]))
+    print("reference 1 rank vs 2 ranks bit-for-bit:", bfb)
+    np.savez_compressed(
+        os.path.join(GOLD, "ref_ne2_2rank_sched.npz"), bfb_1v2=bfb,
+        **{"r%d_%s" % (r, k): sts[r][k] for r in range(2) for k in ("gid", "putmap", "getmap", "reverse", "send_cycles", "move_cycle")})
+
+
+def gather_state_with_gid(outdir, tag, nranks, statics):
+    parts = [po.read_state(os.path.join(outdir, "state_%s_r%04d.bin" % (tag, r))) for r in range(nranks)]
+    gid = np.concatenate([s["gid"] for s in statics]) - 1
+    out = {}
+    for k, v in parts[0].items():
+        if isinstance(v, np.ndarray):
+            cat = np.concatenate([p[k] for p in parts])
+            full = np.empty_like(cat)
+            full[gid] = cat
+            out[k] = full
+    return out
+
+
+def make_long(nranks=6):
+    """ne8 DCMIP 1-1 (12 d) and 1-2 (1 d) as test/run_ne8_tests.sh runs them: norms + mass of the reference."""
+    res = {}
+    for name, test, nsteps, q in (("dcmip1-1", 1, 2592, 4), ("dcmip1-2", 2, 216, 4)):
+        outdir, log = run(ne=8, qsize=q, nsteps=nsteps, tstep=400.0, nu_q=6e16, test=test, dumpfreq=0, nranks=nranks)
+        sts = [po.read_static(os.path.join(outdir, "static_000000_r%04d.bin" % r)) for r in range(nranks)]
+        s0 = gather_state_with_gid(outdir, "000000", nranks, sts)
+        s1 = gather_state_with_gid(outdir, "%06d" % nsteps, nranks, sts)
+        tr = 0 if test == 1 else 1
+        gid = np.concatenate([s["gid"] for s in sts]) - 1
+        lat = np.empty((gid.size, 4, 4)); lon = np.empty((gid.size, 4, 4))
+        lat[gid] = np.concatenate([s["lat"] for s in sts]); lon[gid] = np.concatenate([s["lon"] for s in sts])
+        spheremp = np.empty((gid.size, 4, 4)); spheremp[gid] = np.concatenate([s["spheremp"] for s in sts])
+        res[name] = norms.dcmip_norms_from_qdp(8, lat, lon, s0["qdp"][:, tr], s1["qdp"][:, tr], s1["ps_v"], *po.read_vcoord())
+        res[name]["mass0"] = [float(x) for x in norms.tracer_mass(spheremp, s0["qdp"])]
+        res[name]["mass1"] = [float(x) for x in norms.tracer_mass(spheremp, s1["qdp"])]
+        res[name]["config"] = dict(ne=8, qsize=q, nsteps=nsteps, tstep=400.0, nu_q=6e16, test=test, tracer=tr + 1)
+        print(name, res[name])
+    json.dump(res, open(os.path.join(GOLD, "ref_ne8_norms.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--long", action="store_true")
+    ap.add_argument("--only-long", action="store_true")
+    a = ap.parse_args()
+    if not os.path.exists(HARNESS):
+        subprocess.check_call(["make", "-C", HERE])
+    if not a.only_long:
+        make_ne2()
+    if a.long or a.only_long:
+        make_long()
