@@ -1,0 +1,130 @@
+/* transport_se_hip.h -- C ABI of the MI355X-native tracer-advection engine (libtransport_se_hip.so).
+ *
+ * Drop-in boundary: these entry points are what a Fortran `hip_mod` binds with ISO_C_BINDING in place of
+ * the reference's CUDA-Fortran seam `cuda_mod` (reference src/share/cuda_mod.F90:57-64), which the reference
+ * calls through `#if USE_CUDA_FORTRAN` hooks:
+ *   cuda_mod_init(elem,hybrid,deriv,hvcoord)            prim_driver_mod.F90:686-689   -> tse_init
+ *   copy_qdp_h2d(elem,nt) / copy_qdp_d2h(elem,nt)       prim_driver_mod.F90:781-784,798-801 -> tse_copy_qdp_h2d/_d2h
+ *   euler_step_cuda(np1_qdp,n0_qdp,dt,elem,...,DSSopt,rhs_multiplier)
+ *                                                       prim_advection_mod.F90:715-718 -> tse_euler_step
+ *   qdp_time_avg_cuda(elem,rkstage,n0_qdp,np1_qdp,...)  prim_advection_mod.F90:646-656 -> tse_qdp_time_avg
+ *   vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,..) prim_advection_mod.F90:1279-1282 -> tse_vertical_remap
+ * plus the whole-step call Prim_Advec_Tracers_remap_rk2 (prim_advection_mod.F90:579-640) -> tse_advec_tracers_remap_rk2,
+ * which is the fast path (one call per tracer step, everything stays in HBM).
+ * The Fortran-side binding is shown in INTEGRATION.md and shipped as transport_se_amd/fortran/hip_mod.F90.
+ *
+ * Conventions
+ *   - All functions return 0 on success, nonzero on error (the Fortran side then calls abortmp, as the
+ *     reference does on every failure: parallel_mod.F90:274-287); tse_last_error() gives the message.
+ *   - np = 4, nlev = 72 are compile-time constants exactly as in the reference (dimensions_mod.F90:19,27).
+ *   - Host arrays are passed as the address of element 1's field plus the byte stride between consecutive
+ *     elements (element_t is a fixed-size derived type, element_mod.F90:112-221, so `elem(:)` is strided AoS);
+ *     inside one element the reference's own memory order is assumed (i fastest, then j, k, q, time level).
+ *   - Time-level arguments (n0_qdp, np1_qdp, nt) are the reference's 1-based values (time_mod.F90:85-109).
+ *   - DSSopt: 1 = eta_dot_dpdn, 2 = omega_p, 3 = divdp_proj (prim_advection_mod.F90:454-457).
+ *   - Edge descriptors are the reference's own: putmapP/getmapP are 0-based column offsets into the edge
+ *     buffer, -1 for a missing corner neighbour, reverse is a logical (edge_mod.F90:36-43, schedule_mod.F90:905,929);
+ *     direction index order west,east,south,north,swest,seast,nwest,neast (control_mod.F90:173-181).
+ *   - Neighbour-rank message slots are the reference's Schedule(1)%SendCycle/RecvCycle entries
+ *     (schedtype_mod.F90:7-29): peer rank (0-based), ptrP (1-based first column, as stored), lengthP (columns).
+ */
+#ifndef TRANSPORT_SE_HIP_H
+#define TRANSPORT_SE_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TSE_NP 4
+#define TSE_NLEV 72
+#define TSE_NLEVP 73
+
+typedef struct tse_ctx tse_ctx;
+
+/* Exchange callback = the body of bndry_exchangeV (bndry_mod.F90:21-126): send `sendbuf` slot s
+ * (send_len[s]*nlyr doubles at column offset send_off[s], layer index fastest) to rank send_peer[s], receive the
+ * mirror-image slot into `recvbuf`.  Both pointers are DEVICE pointers.  The library has finished writing
+ * sendbuf (stream-synchronised) when it calls this, and reads recvbuf only after it returns. */
+typedef int (*tse_exchange_fn)(void *user, double *sendbuf, double *recvbuf, int nlyr);
+
+typedef struct {
+  int nelemd;          /* elements on this rank */
+  int qsize;           /* active tracers */
+  int device;          /* HIP device ordinal, -1 = current */
+  double nu_q;         /* control_mod nu_q */
+  int limiter_option;  /* must be 8 (the only limiter wired in the reference: prim_advection_mod.F90:858,880) */
+  int rsplit;          /* control_mod rsplit (vertical remap frequency), informational */
+  const double *Dvv;   /* deriv%Dvv(np,np), Fortran order */
+  const double *hyai;  /* hvcoord%hyai(nlevp) */
+  const double *hybi;  /* hvcoord%hybi(nlevp) */
+  double ps0;          /* hvcoord%ps0 */
+  /* per-element metric terms: address of elem(1)%X and byte stride to elem(2)%X */
+  const double *Dinv;      size_t Dinv_stride;      /* Dinv(2,2,np,np) */
+  const double *metdet;    size_t metdet_stride;    /* (np,np) */
+  const double *rmetdet;   size_t rmetdet_stride;
+  const double *spheremp;  size_t spheremp_stride;
+  const double *rspheremp; size_t rspheremp_stride;
+  /* edge descriptors, dense copies [nelemd][8] */
+  const int *putmapP; const int *getmapP; const int *reverse;
+  /* neighbour-rank slots (0 for a single rank) */
+  int nsend; const int *send_peer; const int *send_ptrP; const int *send_lengthP;
+  int nrecv; const int *recv_peer; const int *recv_ptrP; const int *recv_lengthP;
+  tse_exchange_fn exchange; void *exchange_user;   /* may be NULL when nsend == nrecv == 0 */
+} tse_init_args;
+
+int  tse_init(tse_ctx **ctx, const tse_init_args *args);
+void tse_finalize(tse_ctx *ctx);
+const char *tse_last_error(void);
+int  tse_synchronize(tse_ctx *ctx);
+
+/* elem(ie)%state%Qdp(np,np,nlev,qsize_d,2) <-> device, time level nt (1|2); qsize_d = host array extent */
+int tse_copy_qdp_h2d(tse_ctx *ctx, const double *qdp_elem1, size_t elem_stride, int qsize_d, int nt);
+int tse_copy_qdp_d2h(tse_ctx *ctx, double *qdp_elem1, size_t elem_stride, int qsize_d, int nt);
+
+/* per-step inputs the caller (prim_step/prim_advance_exp) leaves in elem%derived:
+ * vn0(np,np,2,nlev), dp(np,np,nlev), eta_dot_dpdn(np,np,nlevp), omega_p(np,np,nlev); one common element stride per array.
+ * NULL pointers are skipped. */
+int tse_set_derived(tse_ctx *ctx, const double *vn0, size_t vn0_stride, const double *dp, size_t dp_stride,
+                    const double *eta_dot_dpdn, size_t eta_stride, const double *omega_p, size_t omega_stride);
+/* outputs the path writes back into elem: derived%divdp_proj, derived%eta_dot_dpdn (DSS'd, levels 1:nlev),
+ * derived%omega_p (DSS'd), derived%divdp, state%dp3d(:,:,:,np1), state%ps_v(:,:,np1).  NULL pointers are skipped. */
+int tse_get_derived(tse_ctx *ctx, double *divdp_proj, size_t s1, double *eta_dot_dpdn, size_t s2, double *omega_p, size_t s3,
+                    double *divdp, size_t s4, double *dp3d, size_t s5, double *ps_v, size_t s6);
+
+/* Prim_Advec_Tracers_remap_rk2: divdp = div(vn0); 3 x euler_step(dt/2); qdp_time_avg */
+int tse_advec_tracers_remap_rk2(tse_ctx *ctx, double dt, int n0_qdp, int np1_qdp);
+/* the pieces, with the reference's argument meaning */
+int tse_compute_divdp(tse_ctx *ctx);
+int tse_euler_step(tse_ctx *ctx, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier);
+int tse_qdp_time_avg(tse_ctx *ctx, int rkstage, int n0_qdp, int np1_qdp);
+/* vertical_remap; returns 2 on "negative layer thickness" (prim_advection_mod.F90:1323) */
+int tse_vertical_remap(tse_ctx *ctx, double dt, int np1_qdp);
+
+/* qmin/qmax(nlev,qsize,nelemd) module state of prim_advection_mod (:459), for inspection: out[ie][q][k] */
+int tse_get_qminmax(tse_ctx *ctx, double *qmin, double *qmax);
+
+/* ---- "next" rows: on-device prescribed fields + device-resident prim_run loop ---- */
+/* lat/lon: elem(ie)%spherep(np,np)%{lat,lon} dense [nelemd][np*np]; hyam/hybm(nlev) */
+int tse_dcmip_init(tse_ctx *ctx, int test_case /*1: dcmip1-1, 2: dcmip1-2*/, const double *lat, const double *lon,
+                   const double *hyam, const double *hybm);
+/* set_dcmip_*_fields(time=0) + Qdp = Q*dp for both time levels (prim_driver_mod.F90:548-556,646-669) */
+int tse_dcmip_set_initial(tse_ctx *ctx);
+/* what prim_step + prim_advance_exp produce for the step that starts at tl%nstep = nstep */
+int tse_dcmip_step_inputs(tse_ctx *ctx, int nstep, double tstep);
+/* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out */
+int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
+
+/* ---- introspection for tests and the benchmark harness ---- */
+/* device pointers of internal fields: "qdp" [2][nelemd][qsize][nlev][16], "vn0", "dp", "divdp", "divdp_proj",
+ * "eta_dot_dpdn", "omega_p", "dp3d", "ps_v", "qmin", "qmax", "sendbuf", "recvbuf" */
+void *tse_device_ptr(tse_ctx *ctx, const char *name, size_t *nbytes);
+/* accumulated HIP-event time (ms) and launch count of a named kernel group since the last reset; names:
+ * "advance", "dss", "lap", "minmax", "remap", "level", "dcmip", "avg" */
+int tse_kernel_time(tse_ctx *ctx, const char *name, double *ms, long *launches);
+int tse_timing(tse_ctx *ctx, int enable); /* enable/disable + reset per-kernel event timing */
+int tse_halo_layout(tse_ctx *ctx, int *ncol_send, int *ncol_recv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,166 @@
+"""-m gpu parity tests: the HIP path (through the C ABI) against the oracle on the same inputs, and against
+the reference-generated golden fixtures.  Floating-point tolerance: the kernels reorder the 16-point sums
+(tree instead of the reference's serial loop), contract a*b+c into FMAs and use device libm for the
+prescribed winds, so results agree with the fp64 reference to round-off accumulated over the step:
+    TOL_STEP = 5e-13 relative to the field maximum per tracer step.
+(north_star asks for 3 significant figures on the DCMIP norms; see test_gpu_dcmip_norms.py.)"""
+import json
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+import norms
+from gpu_common import elem_from_oracle, make_hip, relerr, sync_inputs_from_oracle
+
+pytestmark = pytest.mark.gpu
+TOL_STEP = 5e-13
+
+
+@pytest.fixture(scope="module")
+def ctx5():
+    o = po.Oracle(2, 5, nu_q=1e19)
+    elem = elem_from_oracle(o, qsize_d=7)  # host array extent qsize_d > qsize, as in the reference (35 vs 4)
+    hip = make_hip(o, elem)
+    yield o, elem, hip
+    hip.close(); o.close()
+
+
+def _upload_state(o, elem, hip):
+    elem["Qdp"][:, :, :o.qsize] = np.moveaxis(o.qdp, 0, 1)
+    hip.copy_qdp_h2d(elem, 1); hip.copy_qdp_h2d(elem, 2)
+    sync_inputs_from_oracle(o, elem)
+    hip.set_derived(elem)
+
+
+def test_stage_by_stage_euler_step(ctx5):
+    """compute_divdp + euler_step x3 + qdp_time_avg with the reference's argument meaning, each stage against
+    the oracle: Qdp(np1), the DSS'd extra variable and the persistent qmin/qmax bounds."""
+    o, elem, hip = ctx5
+    dt = 1800.0
+    o.dcmip_init(1); o.dcmip_step_inputs(1, 0, dt)
+    _upload_state(o, elem, hip)
+    # oracle: replicate Prim_Advec_Tracers_remap_rk2 by hand to see every stage
+    po.lib().orc_advec_tracers_remap_rk2  # (symbol exists)
+    hip.compute_divdp()
+    # oracle divdp
+    import ctypes as C
+    o_stage = po.Oracle(2, 5, nu_q=1e19)
+    o_stage.dcmip_init(1); o_stage.dcmip_step_inputs(1, 0, dt)
+    for e in range(o.nelem):
+        for k in range(72):
+            o_stage.divdp[e, k] = o_stage.divergence_sphere(e, o_stage.vn0[e, k]); o_stage.divdp_proj[e, k] = o_stage.divdp[e, k]
+    for (np1, n0, dss, rhs, var) in ((2, 1, 3, 0, "divdp_proj"), (2, 2, 1, 1, "eta_dot_dpdn"), (2, 2, 2, 2, "omega_p")):
+        o_stage.euler_step(np1, n0, dt / 2, dss, rhs)
+        hip.euler_step(np1, n0, dt / 2, dss, rhs)
+        hip.copy_qdp_d2h(elem, 2); hip.get_derived(elem)
+        assert relerr(elem["Qdp"][:, 1, :5], o_stage.qdp[1]) < TOL_STEP, "stage rhs=%d" % rhs
+        ref = getattr(o_stage, var)
+        got = elem[var]
+        assert relerr(got[:, :72], ref[:, :72]) < TOL_STEP, var
+        qmin, qmax = hip.get_qminmax()
+        assert relerr(qmin, o_stage.qmin) < 1e-12 and relerr(qmax, o_stage.qmax) < 1e-12
+    hip.qdp_time_avg(3, 1, 2)
+    o_stage.qdp[1] = (o_stage.qdp[0] + 2 * o_stage.qdp[1]) / 3
+    hip.copy_qdp_d2h(elem, 2)
+    assert relerr(elem["Qdp"][:, 1, :5], o_stage.qdp[1]) < TOL_STEP
+    # untouched padding tracers of the host array stay zero (qsize_d > qsize)
+    assert not elem["Qdp"][:, :, 5:].any()
+    o_stage.close()
+
+
+def test_six_steps_two_remaps_vs_reference_golden(ctx5, gold):
+    """prim_run_subcycle x2 through the whole-step entry point with host-supplied per-step inputs, against the
+    reference's own output (tests/golden/ref_ne2_dcmip11.npz)."""
+    o, elem, hip = ctx5
+    g = gold("ref_ne2_dcmip11.npz")
+    dt = json.loads(str(g["config"]))["tstep"]
+    o.dcmip_init(1)
+    elem["Qdp"][:, :, :5] = np.moveaxis(o.qdp, 0, 1)
+    hip.copy_qdp_h2d(elem, 1); hip.copy_qdp_h2d(elem, 2)
+    nstep = 0
+    for sub in range(2):
+        for r in range(3):
+            o.dcmip_step_inputs(1, nstep, dt)
+            sync_inputs_from_oracle(o, elem); hip.set_derived(elem)
+            n0 = 1 if nstep % 2 == 0 else 2
+            hip.advec_tracers_remap_rk2(dt, n0, 3 - n0)
+            nstep += 1
+            if nstep == 1:
+                hip.copy_qdp_d2h(elem, 2)
+                assert relerr(elem["Qdp"][:, 1, :5], g["qdp_step1"]) < TOL_STEP
+        hip.vertical_remap(3 * dt, 3 - n0)
+        hip.copy_qdp_d2h(elem, 3 - n0); hip.get_derived(elem)
+        ref = g["qdp_step3"] if sub == 0 else g["qdp_step6"]
+        assert relerr(elem["Qdp"][:, 2 - n0, :5], ref) < 6 * TOL_STEP
+        if sub == 0:
+            assert relerr(elem["dp3d"], g["dp3d_step3"]) < 1e-13 and relerr(elem["ps_v"], g["ps_v_step3"]) < 1e-13
+    # tracer mass conserved over the 6 steps (README:38-44 "Q, Q diss" lines)
+    m0 = norms.tracer_mass(o.spheremp, g["qdp_step1"]); m6 = norms.tracer_mass(o.spheremp, elem["Qdp"][:, 2 - n0, :5])
+    np.testing.assert_allclose(m6, m0, rtol=1e-12)
+
+
+def test_device_dcmip_fields_and_prim_run(ctx5, gold):
+    """on-device prescribed winds/tracers + the device-resident prim_run loop, against oracle and golden"""
+    o, elem, hip = ctx5
+    g = gold("ref_ne2_dcmip11.npz")
+    dt = 1800.0
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm)
+    hip.dcmip_set_initial()
+    o.dcmip_init(1)
+    hip.copy_qdp_d2h(elem, 1)
+    assert relerr(elem["Qdp"][:, 0, :5], o.qdp[0]) < 1e-14
+    for nstep in (0, 1, 4):
+        hip.dcmip_step_inputs(nstep, dt); o.dcmip_step_inputs(1, nstep, dt)
+        assert relerr(hip.fetch("vn0", o.vn0.shape), o.vn0) < 1e-13
+        assert relerr(hip.fetch("eta_dot_dpdn", o.eta_dot_dpdn.shape), o.eta_dot_dpdn) < 1e-12
+        assert np.array_equal(hip.fetch("dp", o.dp.shape), o.dp)
+    nstep = hip.prim_run_subcycle(dt, 2, 0)
+    assert nstep == 6
+    hip.copy_qdp_d2h(elem, 1)
+    assert relerr(elem["Qdp"][:, 0, :5], g["qdp_step6"]) < 10 * TOL_STEP
+
+
+def test_dcmip12_vs_reference_golden(gold):
+    g = gold("ref_ne2_dcmip12.npz")
+    cfg = json.loads(str(g["config"]))
+    o = po.Oracle(cfg["ne"], cfg["qsize"], nu_q=cfg["nu_q"])
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    hip.dcmip_init(2, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+    assert hip.prim_run_subcycle(cfg["tstep"], 1, 0) == 3
+    hip.copy_qdp_d2h(elem, 2)
+    assert relerr(elem["Qdp"][:, 1], g["qdp_step3"]) < 5 * TOL_STEP
+    hip.close(); o.close()
+
+
+def test_negative_layer_thickness_is_reported(ctx5):
+    """vertical_remap aborts with 'negative layer thickness' (prim_advection_mod.F90:1323) -> error return"""
+    from transport_se_amd.hip_mod import TseError
+    o, elem, hip = ctx5
+    o.dcmip_init(1); o.dcmip_step_inputs(1, 0, 1800.0)
+    _upload_state(o, elem, hip)
+    hip.advec_tracers_remap_rk2(1800.0, 1, 2)
+    with pytest.raises(TseError, match="negative layer thickness"):
+        hip.vertical_remap(1.0e9, 2)
+
+
+def test_limiter_edge_cases_through_the_step(ctx5):
+    """infeasible bounds (SSP CFL>1 style), uniform fields and a 0/1 checkerboard through k_advance's limiter:
+    compare with the oracle's limiter_optim_iter_full on identical inputs"""
+    o, elem, hip = ctx5
+    dt = 1800.0
+    o.dcmip_init(1); o.dcmip_step_inputs(1, 0, dt)
+    rng = np.random.default_rng(12345)
+    dpref = o.dp.copy()
+    o.qdp[0][:, 0] = dpref * rng.choice([0.0, 1.0], size=dpref.shape)          # noisy 0/1: many limiter iterations
+    o.qdp[0][:, 1] = dpref * 0.75                                               # uniform: limiter is a no-op
+    o.qdp[0][:, 2] = dpref * rng.uniform(0, 1, size=dpref.shape)
+    o.qdp[0][:, 3] = dpref * np.where(rng.uniform(size=dpref.shape) < 0.05, 50.0, 0.0)  # spikes: bounds get relaxed
+    o.qdp[1] = o.qdp[0]
+    _upload_state(o, elem, hip)
+    o.advec_tracers_remap_rk2(dt, 0)
+    hip.advec_tracers_remap_rk2(dt, 1, 2)
+    hip.copy_qdp_d2h(elem, 2)
+    for q in range(5):
+        assert relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q]) < 20 * TOL_STEP, q

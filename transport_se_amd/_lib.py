@@ -1,0 +1,84 @@
+"""Loader/builder of libtransport_se_hip.so (in-tree; built by __graft_entry__.build())."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libtransport_se_hip.so")
+SRC = [os.path.join(HERE, "csrc", f) for f in ("tse_api.hip", "tse_kernels.h", "tse_device.h")]
+HDR = os.path.join(os.path.dirname(HERE), "include", "transport_se_hip.h")
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class InitArgs(C.Structure):
+    _fields_ = [
+        ("nelemd", C.c_int), ("qsize", C.c_int), ("device", C.c_int), ("nu_q", C.c_double),
+        ("limiter_option", C.c_int), ("rsplit", C.c_int),
+        ("Dvv", C.c_void_p), ("hyai", C.c_void_p), ("hybi", C.c_void_p), ("ps0", C.c_double),
+        ("Dinv", C.c_void_p), ("Dinv_stride", C.c_size_t), ("metdet", C.c_void_p), ("metdet_stride", C.c_size_t),
+        ("rmetdet", C.c_void_p), ("rmetdet_stride", C.c_size_t), ("spheremp", C.c_void_p), ("spheremp_stride", C.c_size_t),
+        ("rspheremp", C.c_void_p), ("rspheremp_stride", C.c_size_t),
+        ("putmapP", C.c_void_p), ("getmapP", C.c_void_p), ("reverse", C.c_void_p),
+        ("nsend", C.c_int), ("send_peer", C.c_void_p), ("send_ptrP", C.c_void_p), ("send_lengthP", C.c_void_p),
+        ("nrecv", C.c_int), ("recv_peer", C.c_void_p), ("recv_ptrP", C.c_void_p), ("recv_lengthP", C.c_void_p),
+        ("exchange", EXCHANGE_FN), ("exchange_user", C.c_void_p),
+    ]
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+    newest = max(os.path.getmtime(p) for p in SRC + [HDR])
+    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+        return SO
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC[0]]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO
+
+
+_lib = None
+
+# every symbol include/transport_se_hip.h declares
+SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse_copy_qdp_h2d", "tse_copy_qdp_d2h",
+           "tse_set_derived", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
+           "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
+           "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
+           "tse_halo_layout"]
+
+
+def lib():
+    """Load the HIP library; raises (never falls back) if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        raise RuntimeError("libtransport_se_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)")
+    L = C.CDLL(SO)
+    vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    L.tse_init.argtypes = [C.POINTER(vp), C.POINTER(InitArgs)]
+    L.tse_finalize.argtypes = [vp]; L.tse_finalize.restype = None
+    L.tse_last_error.restype = C.c_char_p
+    L.tse_synchronize.argtypes = [vp]
+    L.tse_copy_qdp_h2d.argtypes = [vp, vp, sz, i, i]
+    L.tse_copy_qdp_d2h.argtypes = [vp, vp, sz, i, i]
+    L.tse_set_derived.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz]
+    L.tse_get_derived.argtypes = [vp] + [vp, sz] * 6
+    L.tse_advec_tracers_remap_rk2.argtypes = [vp, d, i, i]
+    L.tse_compute_divdp.argtypes = [vp]
+    L.tse_euler_step.argtypes = [vp, i, i, d, i, i]
+    L.tse_qdp_time_avg.argtypes = [vp, i, i, i]
+    L.tse_vertical_remap.argtypes = [vp, d, i]
+    L.tse_get_qminmax.argtypes = [vp, vp, vp]
+    L.tse_dcmip_init.argtypes = [vp, i, vp, vp, vp, vp]
+    L.tse_dcmip_set_initial.argtypes = [vp]
+    L.tse_dcmip_step_inputs.argtypes = [vp, i, d]
+    L.tse_prim_run_subcycle.argtypes = [vp, d, i, C.POINTER(i)]
+    L.tse_device_ptr.argtypes = [vp, C.c_char_p, C.POINTER(sz)]; L.tse_device_ptr.restype = vp
+    L.tse_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_long)]
+    L.tse_timing.argtypes = [vp, i]
+    L.tse_halo_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    _lib = L
+    return L

@@ -1,0 +1,589 @@
+// tse_api.hip -- host side of libtransport_se_hip.so: the C ABI declared in include/transport_se_hip.h.
+//
+// Owns all device memory for the run (as cuda_mod owns qdp_d etc., reference cuda_mod.F90:74-106), converts the
+// reference's edge descriptors (putmapP/getmapP/reverse + Send/RecvCycle slots) into on-device gather tables once
+// at init, and sequences the kernels of tse_kernels.h on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/transport_se_hip.h"
+#include "tse_kernels.h"
+
+using namespace tse;
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+  return 1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+
+struct KTimer { double ms = 0; long n = 0; };
+
+struct tse_ctx {
+  int nelemd = 0, qsize = 0, device = 0, rsplit = 3;
+  double nu_q = 0, ps0 = 0;
+  Dvv_t D;
+  hipStream_t stream = nullptr;
+  // metric + tables
+  double *Dinv = nullptr, *metdet = nullptr, *rmetdet = nullptr, *spheremp = nullptr, *rspheremp = nullptr;
+  double *hyai = nullptr, *hybi = nullptr, *dp0 = nullptr;
+  int2 *dss_tab = nullptr, *send_src = nullptr;
+  int *nbr = nullptr;
+  // state
+  double *qdp = nullptr, *T = nullptr, *B = nullptr;
+  double *vn0 = nullptr, *dp = nullptr, *divdp = nullptr, *divdp_proj = nullptr, *eta = nullptr, *omega_p = nullptr;
+  double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
+  double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
+  int* bad = nullptr;
+  // halo
+  int ncol_send = 0, ncol_recv = 0, nlyr_halo = 0;
+  double *sendbuf = nullptr, *recvbuf = nullptr;
+  bool own_halo = false;
+  tse_exchange_fn exchange = nullptr; void* exchange_user = nullptr;
+  // dcmip
+  int dcmip_test = 0;
+  double *lat = nullptr, *lon = nullptr, *zm = nullptr, *zi = nullptr, *pint = nullptr, *dph = nullptr;
+  // staging + timing
+  std::vector<double> hstage;
+  bool timing = false;
+  std::map<std::string, KTimer> timers;
+  struct Pending { const char* name; hipEvent_t a, b; };
+  std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
+  std::vector<hipEvent_t> free_events;
+  double *lvl_tmp2 = nullptr;
+  size_t lev() const { return (size_t)nelemd * NLEV * 16; }
+  size_t trc() const { return lev() * qsize; }
+  GeoPtrs geo() const { return GeoPtrs{Dinv, metdet, rmetdet, spheremp, rspheremp}; }
+};
+
+const char* tse_last_error(void) { return g_err; }
+
+template <class T>
+static int dalloc(T** p, size_t n) {
+  HIPCHK(hipMalloc((void**)p, n * sizeof(T) > 0 ? n * sizeof(T) : sizeof(T)));
+  return 0;
+}
+template <class T>
+static int upload(T** p, const std::vector<T>& h) {
+  if (dalloc(p, h.size())) return 1;
+  if (!h.empty()) HIPCHK(hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// time a group of launches with HIP events on the launch stream (only when timing is enabled)
+static hipEvent_t get_event(tse_ctx* c) {
+  if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+  hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
+}
+struct Scope {
+  tse_ctx* c; const char* name; hipEvent_t a = nullptr;
+  Scope(tse_ctx* c_, const char* n) : c(c_), name(n) { if (c->timing) { a = get_event(c); (void)hipEventRecord(a, c->stream); } }
+  ~Scope() {
+    if (!a) return;
+    hipEvent_t b = get_event(c);
+    (void)hipEventRecord(b, c->stream);
+    c->pending.push_back({name, a, b});
+  }
+};
+static void resolve_timers(tse_ctx* c) {
+  if (c->pending.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& p : c->pending) {
+    float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+    KTimer& t = c->timers[p.name]; t.ms += ms; t.n += 1;
+    c->free_events.push_back(p.a); c->free_events.push_back(p.b);
+  }
+  c->pending.clear();
+}
+
+static inline int edge_point(int d, int k) {  // d: 0 W, 1 E, 2 S, 3 N  (edge_mod.F90:407-422)
+  switch (d) { case 0: return k * 4 + 0; case 1: return k * 4 + 3; case 2: return k; default: return 12 + k; }
+}
+static inline int corner_point(int d) {  // d: 4 SW, 5 SE, 6 NW, 7 NE
+  switch (d) { case 4: return 0; case 5: return 3; case 6: return 12; default: return 15; }
+}
+
+static void gather_strided(std::vector<double>& out, const double* base, size_t stride_bytes, int n, int cnt) {
+  out.resize((size_t)n * cnt);
+  for (int e = 0; e < n; e++)
+    memcpy(&out[(size_t)e * cnt], (const char*)base + (size_t)e * stride_bytes, sizeof(double) * cnt);
+}
+
+int tse_init(tse_ctx** out, const tse_init_args* a) {
+  if (!out || !a) return fail("tse_init: null argument");
+  if (a->limiter_option != 8) return fail("tse_init: only limiter_option=8 is supported (got %d)", a->limiter_option);
+  if (a->nelemd <= 0 || a->qsize <= 0) return fail("tse_init: nelemd=%d qsize=%d", a->nelemd, a->qsize);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("tse_init: no HIP device (this library has no CPU fallback)");
+  tse_ctx* c = new tse_ctx();
+  if (a->device >= 0) { if (hipSetDevice(a->device) != hipSuccess) { delete c; return fail("hipSetDevice(%d) failed", a->device); } }
+  HIPCHK(hipGetDevice(&c->device));
+  c->nelemd = a->nelemd; c->qsize = a->qsize; c->nu_q = a->nu_q; c->ps0 = a->ps0; c->rsplit = a->rsplit;
+  c->exchange = a->exchange; c->exchange_user = a->exchange_user;
+  memcpy(c->D.d, a->Dvv, sizeof c->D.d);
+  HIPCHK(hipStreamCreate(&c->stream));
+  const int n = a->nelemd;
+  std::vector<double> h;
+  gather_strided(h, a->Dinv, a->Dinv_stride, n, 64);
+  {  // Dinv(a,b,i,j) in Fortran memory = [p][b][a] -> keep as is: [e][p][4] = {D11, D21, D12, D22}
+    if (upload(&c->Dinv, h)) return 1;
+  }
+  gather_strided(h, a->metdet, a->metdet_stride, n, 16);       if (upload(&c->metdet, h)) return 1;
+  gather_strided(h, a->rmetdet, a->rmetdet_stride, n, 16);     if (upload(&c->rmetdet, h)) return 1;
+  gather_strided(h, a->spheremp, a->spheremp_stride, n, 16);   if (upload(&c->spheremp, h)) return 1;
+  gather_strided(h, a->rspheremp, a->rspheremp_stride, n, 16); if (upload(&c->rspheremp, h)) return 1;
+  {
+    std::vector<double> v(a->hyai, a->hyai + NLEVP); if (upload(&c->hyai, v)) return 1;
+    std::vector<double> w(a->hybi, a->hybi + NLEVP); if (upload(&c->hybi, w)) return 1;
+    std::vector<double> d0(NLEV);  // dp0(k), prim_advection_mod.F90:818-819
+    for (int k = 0; k < NLEV; k++) d0[k] = (a->hyai[k + 1] - a->hyai[k]) * a->ps0 + (a->hybi[k + 1] - a->hybi[k]) * a->ps0;
+    if (upload(&c->dp0, d0)) return 1;
+  }
+
+  // ---- edge descriptors -> gather tables -------------------------------------------------------
+  int maxcol = 0;
+  for (int i = 0; i < n * 8; i++) { if (a->putmapP[i] + 4 > maxcol) maxcol = a->putmapP[i] + 4; if (a->getmapP[i] + 4 > maxcol) maxcol = a->getmapP[i] + 4; }
+  for (int s = 0; s < a->nsend; s++) maxcol = std::max(maxcol, a->send_ptrP[s] - 1 + a->send_lengthP[s]);
+  for (int s = 0; s < a->nrecv; s++) maxcol = std::max(maxcol, a->recv_ptrP[s] - 1 + a->recv_lengthP[s]);
+  std::vector<int> own_e(maxcol, -1), own_p(maxcol, -1), send_idx(maxcol, -1), recv_idx(maxcol, -1);
+  for (int e = 0; e < n; e++)
+    for (int d = 0; d < 8; d++) {
+      int pm = a->putmapP[e * 8 + d];
+      if (pm < 0) continue;
+      if (d < 4) {
+        for (int k = 0; k < 4; k++) {  // reversal is applied at pack time (edge_mod.F90:443-485)
+          int col = pm + (a->reverse[e * 8 + d] ? 3 - k : k);
+          own_e[col] = e; own_p[col] = edge_point(d, k);
+        }
+      } else { own_e[pm] = e; own_p[pm] = corner_point(d); }
+    }
+  c->ncol_send = 0;
+  for (int s = 0; s < a->nsend; s++)
+    for (int i = 0; i < a->send_lengthP[s]; i++) send_idx[a->send_ptrP[s] - 1 + i] = c->ncol_send++;
+  c->ncol_recv = 0;
+  for (int s = 0; s < a->nrecv; s++)
+    for (int i = 0; i < a->recv_lengthP[s]; i++) recv_idx[a->recv_ptrP[s] - 1 + i] = c->ncol_recv++;
+  if ((c->ncol_send || c->ncol_recv) && !a->exchange) { return fail("tse_init: neighbour-rank slots given but no exchange callback"); }
+
+  std::vector<int2> send_src(c->ncol_send);
+  for (int col = 0; col < maxcol; col++)
+    if (send_idx[col] >= 0) {
+      if (own_e[col] < 0) return fail("tse_init: send column %d is written by no local element", col);
+      send_src[send_idx[col]] = make_int2(own_e[col], own_p[col]);
+    }
+  auto source_of = [&](int col, int2& s) -> int {
+    if (recv_idx[col] >= 0) { s = make_int2(-(recv_idx[col] + 2), 0); return 0; }
+    if (own_e[col] < 0) return 1;
+    s = make_int2(own_e[col], own_p[col]);
+    return 0;
+  };
+  std::vector<int2> tab((size_t)n * 48, make_int2(-1, 0));
+  std::vector<int> nbr((size_t)n * 8, -1);
+  static const int eorder[4] = {2, 1, 3, 0};  // S, E, N, W  (edge_mod.F90:685-700)
+  static const int corder[4] = {4, 5, 7, 6};  // SW, SE, NE, NW (:723-734)
+  for (int e = 0; e < n; e++) {
+    int cnt[16] = {0};
+    for (int t = 0; t < 4; t++) {
+      int d = eorder[t], gm = a->getmapP[e * 8 + d];
+      if (gm < 0) return fail("tse_init: element %d has no neighbour across edge %d", e, d);
+      for (int k = 0; k < 4; k++) {
+        int2 s;
+        if (source_of(gm + k, s)) return fail("tse_init: element %d edge %d reads column %d that nobody writes", e, d, gm + k);
+        int p = edge_point(d, k);
+        tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = s;
+        if (k == 0) nbr[e * 8 + d] = s.x;  // element-constant min/max: any column of the edge will do
+      }
+    }
+    for (int t = 0; t < 4; t++) {
+      int d = corder[t], gm = a->getmapP[e * 8 + d];
+      if (gm < 0) continue;
+      int2 s;
+      if (source_of(gm, s)) return fail("tse_init: element %d corner %d reads column %d that nobody writes", e, d, gm);
+      int p = corner_point(d);
+      tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = s;
+      nbr[e * 8 + d] = s.x;
+    }
+  }
+  if (upload(&c->dss_tab, tab) || upload(&c->nbr, nbr) || upload(&c->send_src, send_src)) return 1;
+
+  // ---- state -------------------------------------------------------------------------------------
+  const size_t lev = c->lev(), trc = c->trc();
+  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, trc) || dalloc(&c->B, trc)) return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
+  if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
+      dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
+      dalloc(&c->lvl_tmp, lev) || dalloc(&c->lvl_tmp2, lev)) return 1;
+  const size_t mm = (size_t)n * c->qsize * NLEV;
+  if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
+  HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8)); HIPCHK(hipMemset(c->T, 0, trc * 8)); HIPCHK(hipMemset(c->B, 0, trc * 8));
+  HIPCHK(hipMemset(c->vn0, 0, 2 * lev * 8)); HIPCHK(hipMemset(c->dp, 0, lev * 8)); HIPCHK(hipMemset(c->divdp, 0, lev * 8));
+  HIPCHK(hipMemset(c->divdp_proj, 0, lev * 8)); HIPCHK(hipMemset(c->eta, 0, (size_t)n * NLEVP * 16 * 8));
+  HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
+  HIPCHK(hipMemset(c->qmin, 0, mm * 8)); HIPCHK(hipMemset(c->qmax, 0, mm * 8));
+  HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
+  // halo buffers sized for the largest exchange: 3*qsize*nlev layers is what the reference allocates
+  // (prim_advection_mod.F90:488); we need max(qsize*nlev + nlev, 2*qsize*nlev)
+  c->nlyr_halo = std::max(c->qsize * NLEV + NLEV, 2 * c->qsize * NLEV);
+  if (c->ncol_send || c->ncol_recv) {
+    if (dalloc(&c->sendbuf, (size_t)std::max(1, c->ncol_send) * c->nlyr_halo) || dalloc(&c->recvbuf, (size_t)std::max(1, c->ncol_recv) * c->nlyr_halo)) return 1;
+    c->own_halo = true;
+  }
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipDeviceSynchronize());
+  *out = c;
+  return 0;
+}
+
+void tse_finalize(tse_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
+                  c->nbr, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
+                  c->lvl_tmp, c->lvl_tmp2, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
+  resolve_timers(c);
+  for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int tse_synchronize(tse_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+
+int tse_halo_layout(tse_ctx* c, int* ns, int* nr) { if (ns) *ns = c->ncol_send; if (nr) *nr = c->ncol_recv; return 0; }
+
+// ---- host <-> device copies ---------------------------------------------------------------------
+int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, int nt) {
+  if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_h2d: nt=%d qsize_d=%d", nt, qsize_d);
+  const size_t per = (size_t)c->qsize * NLEV * 16;
+  c->hstage.resize((size_t)c->nelemd * per);
+  for (int e = 0; e < c->nelemd; e++)  // Qdp(np,np,nlev,qsize_d,2): time level nt starts qsize_d*nlev*16 doubles in
+    memcpy(&c->hstage[(size_t)e * per], (const char*)q1 + (size_t)e * stride + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, per * 8);
+  HIPCHK(hipMemcpyAsync(c->qdp + (size_t)(nt - 1) * c->trc(), c->hstage.data(), c->hstage.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+int tse_copy_qdp_d2h(tse_ctx* c, double* q1, size_t stride, int qsize_d, int nt) {
+  if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_d2h: nt=%d qsize_d=%d", nt, qsize_d);
+  const size_t per = (size_t)c->qsize * NLEV * 16;
+  c->hstage.resize((size_t)c->nelemd * per);
+  HIPCHK(hipMemcpyAsync(c->hstage.data(), c->qdp + (size_t)(nt - 1) * c->trc(), c->hstage.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int e = 0; e < c->nelemd; e++)
+    memcpy((char*)q1 + (size_t)e * stride + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, &c->hstage[(size_t)e * per], per * 8);
+  return 0;
+}
+static int put_level(tse_ctx* c, double* dev, const double* host, size_t stride, size_t cnt_dev, size_t cnt_host) {
+  if (!host) return 0;
+  c->hstage.assign((size_t)c->nelemd * cnt_dev, 0.0);
+  for (int e = 0; e < c->nelemd; e++) memcpy(&c->hstage[(size_t)e * cnt_dev], (const char*)host + (size_t)e * stride, std::min(cnt_dev, cnt_host) * 8);
+  HIPCHK(hipMemcpyAsync(dev, c->hstage.data(), c->hstage.size() * 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+static int get_level(tse_ctx* c, const double* dev, double* host, size_t stride, size_t cnt_dev, size_t cnt_host) {
+  if (!host) return 0;
+  c->hstage.resize((size_t)c->nelemd * cnt_dev);
+  HIPCHK(hipMemcpyAsync(c->hstage.data(), dev, c->hstage.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (int e = 0; e < c->nelemd; e++) memcpy((char*)host + (size_t)e * stride, &c->hstage[(size_t)e * cnt_dev], std::min(cnt_dev, cnt_host) * 8);
+  return 0;
+}
+int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, size_t s1, const double* eta, size_t s2,
+                    const double* omega_p, size_t s3) {
+  // vn0(np,np,2,nlev) in Fortran memory is [k][c][p]: the device layout
+  if (put_level(c, c->vn0, vn0, s0, 2 * NLEV * 16, 2 * NLEV * 16)) return 1;
+  if (put_level(c, c->dp, dp, s1, NLEV * 16, NLEV * 16)) return 1;
+  if (put_level(c, c->eta, eta, s2, NLEVP * 16, NLEVP * 16)) return 1;
+  if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
+  return 0;
+}
+int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size_t s2, double* omega_p, size_t s3, double* divdp,
+                    size_t s4, double* dp3d, size_t s5, double* ps_v, size_t s6) {
+  if (get_level(c, c->divdp_proj, divdp_proj, s1, NLEV * 16, NLEV * 16)) return 1;
+  if (get_level(c, c->eta, eta, s2, NLEVP * 16, NLEV * 16)) return 1;  // levels 1:nlev only are DSS'd (:835-837)
+  if (get_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
+  if (get_level(c, c->divdp, divdp, s4, NLEV * 16, NLEV * 16)) return 1;
+  if (get_level(c, c->dp3d, dp3d, s5, NLEV * 16, NLEV * 16)) return 1;
+  if (get_level(c, c->ps_v, ps_v, s6, 16, 16)) return 1;
+  return 0;
+}
+int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
+  size_t mm = (size_t)c->nelemd * c->qsize * NLEV;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (qmin) HIPCHK(hipMemcpy(qmin, c->qmin, mm * 8, hipMemcpyDeviceToHost));
+  if (qmax) HIPCHK(hipMemcpy(qmax, c->qmax, mm * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---- the path -----------------------------------------------------------------------------------
+#define LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return fail("%s:%d kernel launch: %s", __FILE__, __LINE__, hipGetErrorString(e_)); } while (0)
+
+int tse_compute_divdp(tse_ctx* c) {
+  Scope s(c, "level");
+  hipLaunchKernelGGL(k_divdp, dim3(c->nelemd), dim3(SLAB_THREADS), 0, c->stream, c->D, c->geo(), c->vn0, c->divdp, c->divdp_proj);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+// bndry_exchangeV on the packed rank-boundary columns (no-op on one rank)
+static int halo_exchange(tse_ctx* c, int nlyr) {
+  if (!c->ncol_send && !c->ncol_recv) return 0;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (c->exchange(c->exchange_user, c->sendbuf, c->recvbuf, nlyr)) return fail("exchange callback failed");
+  return 0;
+}
+
+// min/max over neighbours of qmin/qmax (in place; double-buffered on the device)
+static int neighbor_minmax(tse_ctx* c) {
+  const int m = c->qsize * NLEV;
+  if (c->ncol_send) {
+    size_t tot = (size_t)c->ncol_send * m;
+    hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, m, c->send_src,
+                       c->qmin, c->qmax, c->sendbuf, 2 * m, 0);
+    LAUNCH_CHECK();
+  }
+  if (halo_exchange(c, 2 * m)) return 1;
+  size_t tot = (size_t)c->nelemd * m;
+  hipLaunchKernelGGL(k_nbr_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,
+                     c->qmax, c->qmin2, c->qmax2, c->recvbuf, 2 * m);
+  LAUNCH_CHECK();
+  std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
+  return 0;
+}
+
+// DSS (+ inverse mass matrix) of a tracer-sized field src -> dst, together with the extra level variable
+// (spheremp*var packed behind the tracers: nlyr = qsize*nlev + nlev as edgeAdv_p1, prim_advection_mod.F90:497,911-919)
+static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double* var /* [e][NLEV or NLEVP][16] */, int var_levels,
+                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */) {
+  const int nq = c->qsize * NLEV;
+  const double* var_src = var;
+  if (var && var_levels != NLEV) {  // eta_dot_dpdn carries nlev+1 levels per element; DSS levels 1:nlev (:835-837)
+    HIPCHK(hipMemcpy2DAsync(c->lvl_tmp, NLEV * 16 * 8, var, (size_t)var_levels * 16 * 8, NLEV * 16 * 8, c->nelemd, hipMemcpyDeviceToDevice, c->stream));
+    var_src = c->lvl_tmp;
+  }
+  if (c->ncol_send) {
+    size_t tot = (size_t)c->ncol_send * nq;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, src,
+                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0);
+    LAUNCH_CHECK();
+    if (var) {
+      size_t tv = (size_t)c->ncol_send * NLEV;
+      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var_src,
+                         c->spheremp, c->sendbuf, nq + NLEV, nq);
+      LAUNCH_CHECK();
+    }
+  }
+  if (halo_exchange(c, nq + NLEV)) return 1;
+  {
+    Scope s(c, "dss");
+    const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
+    if (Qn0_avg)
+      hipLaunchKernelGGL(k_dss<1>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
+                         Qn0_avg, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
+    else
+      hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
+    LAUNCH_CHECK();
+  }
+  if (var) {
+    Scope s(c, "level");
+    const int nchunk = (NLEV + DSS_LAYERS - 1) / DSS_LAYERS;
+    // out of place (the source must stay intact while neighbours read it): write a scratch level buffer, copy back
+    double* outbuf = c->lvl_tmp2;
+    hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, NLEV, nchunk, c->dss_tab, c->rspheremp, var_src,
+                       outbuf, (const double*)nullptr, c->recvbuf, nq + NLEV, nq, c->spheremp);
+    LAUNCH_CHECK();
+    if (var_levels == NLEV) HIPCHK(hipMemcpyAsync(var, outbuf, c->lev() * 8, hipMemcpyDeviceToDevice, c->stream));
+    else HIPCHK(hipMemcpy2DAsync(var, (size_t)var_levels * 16 * 8, outbuf, NLEV * 16 * 8, NLEV * 16 * 8, c->nelemd, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return 0;
+}
+
+// one RK stage; fuse_avg: apply qdp_time_avg in the final DSS (whole-step path only)
+static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0) {
+  if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
+  if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
+  double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
+  double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  double* var = DSSopt == 1 ? c->eta : DSSopt == 2 ? c->omega_p : DSSopt == 3 ? c->divdp_proj : nullptr;
+  const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
+  const dim3 grid(c->nelemd), blk(SLAB_THREADS);
+  if (rhs == 0) {
+    {
+      Scope s(c, "minmax");
+      hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      LAUNCH_CHECK();
+    }
+    if (neighbor_minmax(c)) return 1;
+    Scope s(c, "advance");
+    hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    LAUNCH_CHECK();
+  } else if (rhs == 1) {
+    Scope s(c, "advance");
+    hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    LAUNCH_CHECK();
+  } else {
+    {
+      Scope s(c, "lap");
+      hipLaunchKernelGGL(k_lap1, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      LAUNCH_CHECK();
+    }
+    // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1)
+    const int nq = c->qsize * NLEV;
+    if (c->ncol_send) {
+      // message layout of edgeAdvQ3 is (lap, Qmin, Qmax) = 3*qsize*nlev layers (viscosity_mod.F90:389-391); we send the
+      // Laplacian and the bounds as two exchanges of the sizes the halo buffer is dimensioned for
+      size_t tot = (size_t)c->ncol_send * nq;
+      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->B,
+                         (const double*)nullptr, c->sendbuf, nq, 0);
+      LAUNCH_CHECK();
+    }
+    if (halo_exchange(c, nq)) return 1;
+    {
+      Scope s(c, "dss");
+      const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
+      hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, c->B, c->T,
+                         (const double*)nullptr, c->recvbuf, nq, 0, (const double*)nullptr);
+      LAUNCH_CHECK();
+    }
+    if (neighbor_minmax(c)) return 1;
+    Scope s(c, "advance");
+    hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+                       c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    LAUNCH_CHECK();
+  }
+  const double* pre = rhs == 2 ? c->B : c->T;
+  const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
+  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg);
+}
+
+int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
+  return euler_step_impl(c, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier, false, 0);
+}
+
+int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
+  Scope s(c, "avg");
+  size_t n = c->trc();
+  hipLaunchKernelGGL(k_time_avg, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
+                     c->qdp + (size_t)(n0_qdp - 1) * n, c->qdp + (size_t)(np1_qdp - 1) * n);
+  LAUNCH_CHECK();
+  return 0;
+}
+
+int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) {
+  if (n0_qdp == np1_qdp) return fail("advec_tracers_remap_rk2: n0_qdp == np1_qdp");
+  if (tse_compute_divdp(c)) return 1;
+  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp)) return 1;
+  return 0;
+}
+
+int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
+  if (np1_qdp < 1 || np1_qdp > 2) return fail("vertical_remap: np1_qdp=%d", np1_qdp);
+  {
+    Scope s(c, "remap");
+    hipLaunchKernelGGL(k_remap, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp + (size_t)(np1_qdp - 1) * c->trc(), c->bad);
+    LAUNCH_CHECK();
+  }
+  int bad = 0;
+  HIPCHK(hipMemcpyAsync(&bad, c->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (bad) {
+    HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
+    fail("negative layer thickness.  timestep or remap time too large");
+    return 2;
+  }
+  return 0;
+}
+
+// ---- prescribed fields + device-resident driver ---------------------------------------------------
+int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, const double* hyam, const double* hybm) {
+  if (test != 1 && test != 2) return fail("tse_dcmip_init: test_case=%d", test);
+  c->dcmip_test = test;
+  const double H = 287.04 * 300.0 / 9.80616, P0 = 100000.0;
+  std::vector<double> hyai(NLEVP), hybi(NLEVP);
+  HIPCHK(hipMemcpy(hyai.data(), c->hyai, NLEVP * 8, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hybi.data(), c->hybi, NLEVP * 8, hipMemcpyDeviceToHost));
+  std::vector<double> zm(NLEV), zi(NLEVP), pint(NLEVP), dph(NLEV);
+  for (int k = 0; k < NLEVP; k++) { zi[k] = H * log(1.0 / (hyai[k] + hybi[k])); pint[k] = P0 * exp(-zi[k] / H); }
+  for (int k = 0; k < NLEV; k++) {
+    zm[k] = H * log(1.0 / (hyam[k] + hybm[k]));
+    dph[k] = (hyai[k + 1] - hyai[k]) * c->ps0 + (hybi[k + 1] - hybi[k]) * pint[NLEV];
+  }
+  std::vector<double> la(lat, lat + (size_t)c->nelemd * 16), lo(lon, lon + (size_t)c->nelemd * 16);
+  void* old[] = {c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+  for (void* p : old) if (p) (void)hipFree(p);
+  if (upload(&c->lat, la) || upload(&c->lon, lo) || upload(&c->zm, zm) || upload(&c->zi, zi) || upload(&c->pint, pint) || upload(&c->dph, dph)) return 1;
+  return 0;
+}
+int tse_dcmip_set_initial(tse_ctx* c) {
+  if (!c->dcmip_test) return fail("tse_dcmip_set_initial: call tse_dcmip_init first");
+  Scope s(c, "dcmip");
+  size_t tot = c->lev();
+  hipLaunchKernelGGL(k_dcmip_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->dcmip_test, c->lat,
+                     c->lon, c->zm, c->pint, c->dph, c->qdp, c->qdp + c->trc(), c->dp3d, c->ps_v);
+  LAUNCH_CHECK();
+  return 0;
+}
+int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
+  if (!c->dcmip_test) return fail("tse_dcmip_step_inputs: call tse_dcmip_init first");
+  Scope s(c, "dcmip");
+  size_t tot = (size_t)c->nelemd * NLEVP * 16;
+  double t_wind = (nstep > 0 ? nstep - 1 : 0) * tstep, t_now = nstep * tstep;
+  hipLaunchKernelGGL(k_dcmip_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
+                     c->lat, c->lon, c->zm, c->zi, c->pint, c->vn0, c->dp, c->eta, c->omega_p);
+  LAUNCH_CHECK();
+  return 0;
+}
+int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
+  int nstep = *nstep_io;
+  for (int s = 0; s < nsub; s++) {
+    int n0 = 1, np1 = 2;
+    for (int r = 0; r < c->rsplit; r++) {
+      if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
+      if (nstep % 2 == 0) { n0 = 1; np1 = 2; } else { n0 = 2; np1 = 1; }  // TimeLevel_Qdp, time_mod.F90:85-109
+      if (tse_advec_tracers_remap_rk2(c, tstep, n0, np1)) return 1;
+      nstep++;
+    }
+    int rc = tse_vertical_remap(c, tstep * c->rsplit, np1);
+    if (rc) { *nstep_io = nstep; return rc; }
+  }
+  *nstep_io = nstep;
+  return 0;
+}
+
+// ---- introspection ------------------------------------------------------------------------------
+void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
+  struct Ent { const char* n; void* p; size_t b; };
+  const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8;
+  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, trc}, {"B", c->B, trc}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
+                {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
+                {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},
+                {"qmax", c->qmax, mm}, {"sendbuf", c->sendbuf, (size_t)c->ncol_send * c->nlyr_halo * 8},
+                {"recvbuf", c->recvbuf, (size_t)c->ncol_recv * c->nlyr_halo * 8}};
+  for (auto& e : ents) if (!strcmp(e.n, name)) { if (nbytes) *nbytes = e.b; return e.p; }
+  if (nbytes) *nbytes = 0;
+  return nullptr;
+}
+int tse_timing(tse_ctx* c, int enable) { resolve_timers(c); c->timing = enable != 0; c->timers.clear(); return 0; }
+int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {
+  resolve_timers(c);
+  auto it = c->timers.find(name);
+  if (it == c->timers.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return 0; }
+  if (ms) *ms = it->second.ms; if (launches) *launches = it->second.n;
+  return 0;
+}

@@ -1,0 +1,185 @@
+// tse_device.h -- device-side building blocks of the gfx950 tracer-advection kernels.
+//
+// Thread layout used by every slab kernel ("row-per-lane"): one lane owns one row j (4 GLL points, i = 0..3,
+// 32 contiguous bytes) of a 4x4 slab; the 4 lanes of a DPP quad own the 4 rows of one slab, so a 64-wide
+// wavefront covers 16 slabs (16 consecutive levels) and reads/writes 2 KiB contiguous per instruction pair
+// (two global_load_dwordx4 per lane).  Contractions along i are in-register; contractions along j and the
+// 16-point reductions of the limiter are quad_perm DPP moves (no LDS, no ds_bpermute).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define NP 4
+#define NLEV 72
+#define NLEVP 73
+
+namespace tse {
+
+constexpr double RREARTH = 1.0 / 6.376e6;  // physical_constants.F90:22,34
+
+struct Dvv_t { double d[16]; };  // d[l*4+i] = Dvv(i,l), passed by value (lives in SGPRs)
+
+// one DPP quad_perm move of a double (two v_mov_b32_dpp); CTRL = quad_perm selector byte
+template <int CTRL>
+__device__ __forceinline__ double dppq(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// broadcast quad lane M to the 4 lanes of the quad
+template <int M>
+__device__ __forceinline__ double quad_bcast(double x) { return dppq<M * 0x55>(x); }
+// butterfly reductions over the 4 lanes of a quad; every lane ends with the bit-identical result
+__device__ __forceinline__ double quad_sum(double x) { x += dppq<0xB1>(x); x += dppq<0x4E>(x); return x; }
+__device__ __forceinline__ double quad_min(double x) { x = fmin(x, dppq<0xB1>(x)); x = fmin(x, dppq<0x4E>(x)); return x; }
+__device__ __forceinline__ double quad_max(double x) { x = fmax(x, dppq<0xB1>(x)); x = fmax(x, dppq<0x4E>(x)); return x; }
+
+__device__ __forceinline__ void load4(const double* __restrict__ p, double v[4]) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+  double2 a = q[0], b = q[1];
+  v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+}
+__device__ __forceinline__ void store4(double* __restrict__ p, const double v[4]) {
+  double2* q = reinterpret_cast<double2*>(p);
+  q[0] = make_double2(v[0], v[1]);
+  q[1] = make_double2(v[2], v[3]);
+}
+
+// per-lane geometry of row j of element e
+struct RowGeo {
+  double Di11[4], Di21[4], Di12[4], Di22[4];  // Dinv(a,b,i,j)
+  double metdet[4], rmetdet[4], spheremp[4];
+  double dcol[4];  // dcol[m] = Dvv(m, j)   (sum over the row index in d/dy)
+  double drow[4];  // drow[m] = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
+};
+
+__device__ __forceinline__ void load_row_geo(RowGeo& g, const Dvv_t& D, const double* __restrict__ Dinv,
+                                             const double* __restrict__ metdet, const double* __restrict__ rmetdet,
+                                             const double* __restrict__ spheremp, int e, int j) {
+  const double* di = Dinv + ((size_t)e * 16 + j * 4) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double2 a = reinterpret_cast<const double2*>(di)[2 * i], b = reinterpret_cast<const double2*>(di)[2 * i + 1];
+    g.Di11[i] = a.x; g.Di21[i] = a.y; g.Di12[i] = b.x; g.Di22[i] = b.y;
+  }
+  load4(metdet + (size_t)e * 16 + j * 4, g.metdet);
+  load4(rmetdet + (size_t)e * 16 + j * 4, g.rmetdet);
+  load4(spheremp + (size_t)e * 16 + j * 4, g.spheremp);
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    g.dcol[m] = j == 0 ? D.d[m] : j == 1 ? D.d[4 + m] : j == 2 ? D.d[8 + m] : D.d[12 + m];
+    g.drow[m] = j == 0 ? D.d[m * 4] : j == 1 ? D.d[m * 4 + 1] : j == 2 ? D.d[m * 4 + 2] : D.d[m * 4 + 3];
+  }
+}
+
+// dx[l] = sum_i Dvv(i,l) a[i]  (in-register) ;  dy[i] = sum_m Dvv(m,j) b(i,m)  (quad broadcast of rows)
+__device__ __forceinline__ void deriv_xy(const Dvv_t& D, const RowGeo& g, const double a[4], const double b[4],
+                                         double dx[4], double dy[4]) {
+#pragma unroll
+  for (int l = 0; l < 4; l++) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) s = s + D.d[l * 4 + i] * a[i];
+    dx[l] = s;
+  }
+  double r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    r0[i] = quad_bcast<0>(b[i]); r1[i] = quad_bcast<1>(b[i]); r2[i] = quad_bcast<2>(b[i]); r3[i] = quad_bcast<3>(b[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double s = 0.0;
+    s = s + g.dcol[0] * r0[i]; s = s + g.dcol[1] * r1[i]; s = s + g.dcol[2] * r2[i]; s = s + g.dcol[3] * r3[i];
+    dy[i] = s;
+  }
+}
+
+// divergence_sphere (derivative_mod.F90:2364-2414) of v = (v1,v2) at the lane's 4 points
+__device__ __forceinline__ void divergence_sphere_row(const Dvv_t& D, const RowGeo& g, const double v1[4],
+                                                      const double v2[4], double div[4]) {
+  double gv1[4], gv2[4], dx[4], dy[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    gv1[i] = g.metdet[i] * (g.Di11[i] * v1[i] + g.Di12[i] * v2[i]);
+    gv2[i] = g.metdet[i] * (g.Di21[i] * v1[i] + g.Di22[i] * v2[i]);
+  }
+  deriv_xy(D, g, gv1, gv2, dx, dy);
+#pragma unroll
+  for (int i = 0; i < 4; i++) div[i] = (dx[i] + dy[i]) * (g.rmetdet[i] * RREARTH);
+}
+
+// laplace_sphere_wk = divergence_sphere_wk(gradient_sphere(s))  (derivative_mod.F90:1660-1700,2027-2097,2418-2460)
+__device__ __forceinline__ void laplace_sphere_wk_row(const Dvv_t& D, const RowGeo& g, const double s[4], double lap[4]) {
+  double dx[4], dy[4], w1[4], w2[4];
+  deriv_xy(D, g, s, s, dx, dy);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    double v1 = dx[i] * RREARTH, v2 = dy[i] * RREARTH;
+    double ds1 = g.Di11[i] * v1 + g.Di21[i] * v2;   // gradient_sphere: Dinv^T
+    double ds2 = g.Di12[i] * v1 + g.Di22[i] * v2;
+    double vt1 = g.Di11[i] * ds1 + g.Di12[i] * ds2; // divergence_sphere_wk: latlon -> contra
+    double vt2 = g.Di21[i] * ds1 + g.Di22[i] * ds2;
+    w1[i] = g.spheremp[i] * vt1;
+    w2[i] = g.spheremp[i] * vt2;
+  }
+  // div(m,n) = - sum_j [ w1(j,n) Dvv(m,j) + w2(m,j) Dvv(n,j) ] * rrearth ; n = my row
+  double r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    r0[i] = quad_bcast<0>(w2[i]); r1[i] = quad_bcast<1>(w2[i]); r2[i] = quad_bcast<2>(w2[i]); r3[i] = quad_bcast<3>(w2[i]);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    double d = 0.0;
+    d = d - (w1[0] * D.d[0 * 4 + m] + r0[m] * g.drow[0]) * RREARTH;
+    d = d - (w1[1] * D.d[1 * 4 + m] + r1[m] * g.drow[1]) * RREARTH;
+    d = d - (w1[2] * D.d[2 * 4 + m] + r2[m] * g.drow[2]) * RREARTH;
+    d = d - (w1[3] * D.d[3 * 4 + m] + r3[m] * g.drow[3]) * RREARTH;
+    lap[m] = d;
+  }
+}
+
+// limiter_optim_iter_full (prim_advection_mod.F90:976-1094) on one slab spread over a quad.
+// x[i] = ptens/dpmass at the lane's 4 points, c[i] = sphweights*dpmass, sumc = sum(c) over the slab.
+// minp/maxp are relaxed in place (intent(inout) in the reference).  The 16-point sums are tree sums
+// (4 in-lane + quad butterfly) instead of the reference's serial k1 loop.
+__device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], double sumc, double& minp, double& maxp) {
+  const double tol_limiter = (double)5e-14f;
+  if (!(sumc > 0.0)) return;  // whole quad takes the same branch
+  double mass = quad_sum(((c[0] * x[0] + c[1] * x[1]) + c[2] * x[2]) + c[3] * x[3]);
+  if (mass < minp * sumc) minp = mass / sumc;
+  if (mass > maxp * sumc) maxp = mass / sumc;
+  for (int iter = 1; iter <= NP * NP - 1; iter++) {
+    double addmass = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (x[i] > maxp) { addmass = addmass + (x[i] - maxp) * c[i]; x[i] = maxp; }
+      if (x[i] < minp) { addmass = addmass - (minp - x[i]) * c[i]; x[i] = minp; }
+    }
+    addmass = quad_sum(addmass);
+    bool done = fabs(addmass) <= tol_limiter * fabs(mass);
+    if (__all(done)) break;  // wave-uniform exit; slabs already converged are left untouched below
+    double w = 0.0;
+    if (addmass > 0.0) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (x[i] < maxp) w = w + c[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) if (x[i] > minp) w = w + c[i];
+    }
+    w = quad_sum(w);
+    if (!done) {
+      double inc = addmass / w;
+      if (addmass > 0.0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (x[i] < maxp) x[i] = x[i] + inc;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (x[i] > minp) x[i] = x[i] + inc;
+      }
+    }
+  }
+}
+
+}  // namespace tse

@@ -1,0 +1,522 @@
+// tse_kernels.h -- the gfx950 kernels of the tracer hot path (included once by tse_api.hip).
+//
+// HBM layout (all fp64, point index p = j*4+i fastest):
+//   tracer fields  Qdp[tl][e][q][k][p], T[e][q][k][p] (pre-DSS scratch), B[e][q][k][p] (biharmonic scratch)
+//   level fields   dp, divdp, divdp_proj, omega_p, dp3d [e][k][p]; vn0[e][k][c][p]; eta_dot_dpdn[e][73][p]
+//   bounds         qmin/qmax[e][q][k]
+//   metric         Dinv[e][p][4], metdet/rmetdet/spheremp/rspheremp[e][p]
+// Every slab kernel uses the row-per-lane layout of tse_device.h: block = one element, thread = (level k, row j),
+// looping over the tracers so that everything that depends on (e,k) only -- Vstar, dp, dp_star, the metric rows --
+// is computed once and stays in registers for all qsize tracers.
+#pragma once
+#include "tse_device.h"
+
+namespace tse {
+
+constexpr int SLAB_THREADS = 320;  // 72 levels x 4 rows = 288 active lanes (4.5 waves)
+
+struct GeoPtrs {
+  const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// divdp = divdp_proj = divergence_sphere(vn0)   (prim_advection_mod.F90:614-623)
+__global__ __launch_bounds__(SLAB_THREADS) void k_divdp(Dvv_t D, GeoPtrs G, const double* __restrict__ vn0,
+                                                        double* __restrict__ divdp, double* __restrict__ divdp_proj) {
+  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  RowGeo g;
+  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  double v1[4], v2[4], div[4];
+  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, v1);
+  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, v2);
+  divergence_sphere_row(D, g, v1, v2, div);
+  if (k < NLEV) {
+    store4(divdp + ((size_t)e * NLEV + k) * 16 + j * 4, div);
+    store4(divdp_proj + ((size_t)e * NLEV + k) * 16 + j * 4, div);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
+__global__ __launch_bounds__(SLAB_THREADS) void k_qminmax(int qsize, double rdt /* rhs_multiplier*dt */,
+                                                          const double* __restrict__ Qn0, const double* __restrict__ dp,
+                                                          const double* __restrict__ divdp_proj,
+                                                          double* __restrict__ qmin, double* __restrict__ qmax) {
+  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  double dpk[4], dv[4];
+  const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
+  load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
+#pragma unroll
+  for (int i = 0; i < 4; i++) dpk[i] = dpk[i] - rdt * dv[i];
+  for (int q = 0; q < qsize; q++) {
+    double x[4];
+    load4(Qn0 + (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = x[i] / dpk[i];
+    double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
+    double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+    if (j == 0 && k < NLEV) {
+      qmin[((size_t)e * qsize + q) * NLEV + k] = mn;
+      qmax[((size_t)e * qsize + q) * NLEV + k] = mx;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// neighbor_minmax / min-max half of biharmonic_wk_scalar_minmax (viscosity_mod.F90:748-816,389-432):
+// min/max over the element and its <= 8 neighbours.  nbr[e][8]: >= 0 local element, -1 none,
+// <= -2 remote: column -(v+2) of the received halo (layer index = (q*NLEV+k), min set then max set).
+__global__ void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr, const double* __restrict__ in_min,
+                             const double* __restrict__ in_max, double* __restrict__ out_min, double* __restrict__ out_max,
+                             const double* __restrict__ recvbuf, int nlyr_halo) {
+  const size_t m = (size_t)qsize * NLEV;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)nelemd * m) return;
+  const int e = (int)(t / m);
+  const size_t l = t % m;
+  double mn = in_min[t], mx = in_max[t];
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    int n = nbr[e * 8 + d];
+    if (n >= 0) { mn = fmin(mn, in_min[(size_t)n * m + l]); mx = fmax(mx, in_max[(size_t)n * m + l]); }
+    else if (n <= -2) {
+      size_t col = (size_t)(-(n + 2));
+      mn = fmin(mn, recvbuf[col * nlyr_halo + l]);
+      mx = fmax(mx, recvbuf[col * nlyr_halo + m + l]);
+    }
+  }
+  out_min[t] = mn; out_max[t] = mx;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the fused euler_step advance (prim_advection_mod.F90:834-902) for one RK stage:
+//   Vstar = vn0/dp, dp_star = dp - dt*divdp, Qtens = Qdp - dt*div(Vstar*Qdp) [+ biharmonic], limiter8, *spheremp.
+// RHS = rhs_multiplier.  RHS==1 folds in the local min/max update (:781-793).  RHS==2 folds in the second
+// Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
+// `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
+template <int RHS>
+__global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
+                                                          const double* __restrict__ Qn0, const double* __restrict__ lap,
+                                                          double* __restrict__ Tout, const double* __restrict__ vn0,
+                                                          const double* __restrict__ dp, const double* __restrict__ divdp,
+                                                          const double* __restrict__ divdp_proj, double* __restrict__ qmin,
+                                                          double* __restrict__ qmax, const double* __restrict__ dp0) {
+  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  RowGeo g;
+  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
+  double dpk[4], vs1[4], vs2[4], dps[4], c[4], t0[4], t1[4];
+  load4(dp + lo, dpk); load4(divdp_proj + lo, t0); load4(divdp + lo, t1);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { dpk[i] = dpk[i] - RHS * dt * t0[i]; dps[i] = dpk[i] - dt * t1[i]; }
+  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
+  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { vs1[i] = vs1[i] / dpk[i]; vs2[i] = vs2[i] / dpk[i]; c[i] = g.spheremp[i] * dps[i]; }
+  const double sumc = quad_sum(((c[0] + c[1]) + c[2]) + c[3]);
+  const double visc = RHS == 2 ? -3.0 * dt * nu_q * dp0[kc] : 0.0;  // -rhs_viss*dt*nu_q*dp0
+
+  for (int q = 0; q < qsize; q++) {
+    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
+    const size_t mi = ((size_t)e * qsize + q) * NLEV + kc;
+    double qn[4], g1[4], g2[4], div[4], x[4];
+    load4(Qn0 + so, qn);
+    double minp = qmin[mi], maxp = qmax[mi];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { g1[i] = vs1[i] * qn[i]; g2[i] = vs2[i] * qn[i]; }
+    divergence_sphere_row(D, g, g1, g2, div);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = qn[i] - dt * div[i];
+    if (RHS == 1) {
+      double qq[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) qq[i] = qn[i] / dpk[i];
+      minp = fmin(minp, quad_min(fmin(fmin(qq[0], qq[1]), fmin(qq[2], qq[3]))));
+      maxp = fmax(maxp, quad_max(fmax(fmax(qq[0], qq[1]), fmax(qq[2], qq[3]))));
+    }
+    if (RHS == 2) {
+      double s[4], l2[4];
+      load4(lap + so, s);
+      laplace_sphere_wk_row(D, g, s, l2);
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = x[i] + visc * l2[i] / g.spheremp[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = x[i] / dps[i];
+    limiter8_quad(x, c, sumc, minp, maxp);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = g.spheremp[i] * (x[i] * dps[i]);
+    if (k < NLEV) {
+      store4(Tout + so, x);
+      if (j == 0) { qmin[mi] = minp; qmax[mi] = maxp; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
+// Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
+__global__ __launch_bounds__(SLAB_THREADS) void k_lap1(Dvv_t D, GeoPtrs G, int qsize, double rdt,
+                                                       const double* __restrict__ Qn0, double* __restrict__ Bout,
+                                                       const double* __restrict__ dp, const double* __restrict__ divdp_proj,
+                                                       double* __restrict__ qmin, double* __restrict__ qmax) {
+  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  RowGeo g;
+  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
+  double dpk[4], dv[4];
+  load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
+#pragma unroll
+  for (int i = 0; i < 4; i++) dpk[i] = dpk[i] - rdt * dv[i];
+  for (int q = 0; q < qsize; q++) {
+    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
+    double x[4], l1[4];
+    load4(Qn0 + so, x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = x[i] / dpk[i];
+    double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
+    double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+    laplace_sphere_wk_row(D, g, x, l1);
+    if (k < NLEV) {
+      store4(Bout + so, l1);
+      if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// DSS as a gather (edgeVpack + bndry_exchangeV + edgeVunpack, edge_mod.F90:366-511,648-742), fused with the
+// inverse mass matrix (prim_advection_mod.F90:929-960) and, for MODE 1, with qdp_time_avg (:645-662).
+// Each element adds its neighbours' values in the reference's fixed order (all S, E, N, W, then SW, SE, NE, NW),
+// so results do not depend on how elements are distributed over GPUs.
+//   tab[e][16][3] = {source element (>=0 local, -1 none, <=-2 remote column -(v+2)), source point}
+//   src/dst: [e][nlyr][16]; remote values come from recvbuf[col][nlyr_halo] at layer offset lyr0+l.
+// Block = (element, chunk of 64 layers), thread = (layer, row j).
+constexpr int DSS_THREADS = 256;
+constexpr int DSS_LAYERS = DSS_THREADS / 4;
+template <int MODE>
+__global__ __launch_bounds__(DSS_THREADS) void k_dss(int nlyr, int nchunk, const int2* __restrict__ tab,
+                                                     const double* __restrict__ rspheremp, const double* __restrict__ src,
+                                                     double* __restrict__ dst, const double* __restrict__ Qn0,
+                                                     const double* __restrict__ recvbuf, int nlyr_halo, int lyr0,
+                                                     const double* __restrict__ scale_in /* spheremp or null */) {
+  const int e = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int tid = threadIdx.x, j = tid & 3;
+  int l = chunk * DSS_LAYERS + (tid >> 2);
+  const bool active = l < nlyr;
+  if (!active) l = nlyr - 1;
+  __shared__ int2 stab[48];
+  if (tid < 48) stab[tid] = tab[(size_t)e * 48 + tid];
+  __syncthreads();
+  double v[4], rs[4];
+  const size_t off = ((size_t)e * nlyr + l) * 16 + j * 4;
+  load4(src + off, v);
+  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  if (scale_in) {
+    double sm[4];
+    load4(scale_in + (size_t)e * 16 + j * 4, sm);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = sm[i] * v[i];
+  }
+#pragma unroll
+  for (int cidx = 0; cidx < 3; cidx++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int2 s = stab[(j * 4 + i) * 3 + cidx];
+      if (s.x >= 0) {
+        double a = src[((size_t)s.x * nlyr + l) * 16 + s.y];
+        if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
+        v[i] = v[i] + a;
+      } else if (s.x <= -2) {
+        v[i] = v[i] + recvbuf[(size_t)(-(s.x + 2)) * nlyr_halo + lyr0 + l];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
+  if (MODE == 1) {
+    double q0[4];
+    load4(Qn0 + off, q0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (q0[i] + 2 * v[i]) / 3;  // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
+  }
+  if (active) store4(dst + off, v);
+}
+
+// pack the rank-boundary columns of a [e][nlyr][16] field into sendbuf[col][nlyr_halo] (layer fastest, the
+// reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
+__global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
+                       const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)ncol * nlyr) return;
+  int col = (int)(t / nlyr), l = (int)(t % nlyr);
+  int2 s = send_src[col];
+  double a = src[((size_t)s.x * nlyr + l) * 16 + s.y];
+  if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
+  sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
+}
+// element-constant min/max fields packed the way neighbor_minmax does (viscosity_mod.F90:764-774)
+__global__ void k_pack_minmax(int ncol, int m, const int2* __restrict__ send_src, const double* __restrict__ qmin,
+                              const double* __restrict__ qmax, double* __restrict__ sendbuf, int nlyr_halo, int lyr0) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)ncol * m) return;
+  int col = (int)(t / m), l = (int)(t % m);
+  int e = send_src[col].x;
+  sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = qmin[(size_t)e * m + l];
+  sendbuf[(size_t)col * nlyr_halo + lyr0 + m + l] = qmax[(size_t)e * m + l];
+}
+
+// qdp_time_avg alone (prim_advection_mod.F90:645-662), for the stage-by-stage API
+__global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0, double* __restrict__ Qnp1) {
+  size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (t >= n) return;
+  double2 a = *reinterpret_cast<const double2*>(Qn0 + t), b = *reinterpret_cast<double2*>(Qnp1 + t);
+  b.x = (a.x + (rkstage - 1) * b.x) / rkstage;
+  b.y = (a.y + (rkstage - 1) * b.y) / rkstage;
+  *reinterpret_cast<double2*>(Qnp1 + t) = b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// vertical_remap + remap_Q_ppm (prim_advection_mod.F90:1242-1330, 98-356).  Block = element.
+// Phase 1 (grid part, once per column): dp3d, ps_v, target dp, interface sums, bracket search kid/z2, the 10 PPM
+// grid coefficients per level -> LDS.  Phase 2: thread = (tracer q, column p) streams down the column keeping a
+// 5-cell window of cell means in registers (kid(k) >= k-1 by construction of the search, :160-166, so the
+// in-place update never overtakes the reads).
+constexpr int REMAP_THREADS = 576;
+struct RemapLds {
+  double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
+  double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
+  double z2[NLEV][16];
+  double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
+  int kid[NLEV][16];
+};
+__device__ __forceinline__ double ppm_dma(const double* d /* dx1..3 */, double am, double a0, double ap) {
+  double da = d[0] * (d[1] * (ap - a0) + d[2] * (a0 - am));
+  double m = fmin(fabs(da), fmin(2. * fabs(a0 - am), 2. * fabs(ap - a0)));
+  double r = copysign(m, da);
+  if ((ap - a0) * (a0 - am) <= 0.) r = 0.;
+  return r;
+}
+__global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
+                                                         const double* __restrict__ hybi, const double* __restrict__ dp,
+                                                         const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
+                                                         double* __restrict__ ps_v, double* __restrict__ Q,
+                                                         int* __restrict__ bad) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
+  const int e = blockIdx.x, tid = threadIdx.x;
+  // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
+  for (int w = tid; w < NLEV * 16; w += REMAP_THREADS) {
+    size_t o = (size_t)e * NLEV * 16 + w;
+    double d = dp[o] - dt * divdp_proj[o];
+    dp3d[o] = d;
+    S.dpo[(w >> 4) + 2][w & 15] = d;
+    if (d < 0) atomicOr(bad, 1);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int p = tid;
+    double s = 0.0;
+    for (int k = 0; k < NLEV; k++) s += S.dpo[k + 2][p];
+    double ps = hyai[0] * ps0 + s;
+    ps_v[(size_t)e * 16 + p] = ps;
+    double pio_prev = 0.0;
+    S.pio[0][p] = 0.0;
+    for (int k = 1; k <= NLEV; k++) { pio_prev = pio_prev + S.dpo[k + 1][p]; S.pio[k][p] = pio_prev; }
+    S.pio[NLEV + 1][p] = pio_prev + 1.;
+    for (int k = 1; k <= 2; k++) { S.dpo[2 - k][p] = S.dpo[k + 1][p]; S.dpo[NLEV + k + 1][p] = S.dpo[NLEV + 2 - k][p]; }
+    double pin = 0.0;
+    int kk = 1;
+    for (int k = 1; k <= NLEV; k++) {
+      double dpn = (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
+      pin = pin + dpn;
+      double pin_k1 = (k == NLEV) ? S.pio[NLEV][p] : pin;  // pin(nlev+1) = pio(nlev+1)
+      kk = k;
+      while (S.pio[kk - 1][p] <= pin_k1) kk++;
+      kk--;
+      if (kk == NLEV + 1) kk = NLEV;
+      S.kid[k - 1][p] = kk;
+      S.z2[k - 1][p] = (pin_k1 - (S.pio[kk - 1][p] + S.pio[kk][p]) * 0.5) / S.dpo[kk + 1][p];
+    }
+  }
+  __syncthreads();
+  // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260), one (j,p) per work item
+  for (int w = tid; w < (NLEV + 2) * 16; w += REMAP_THREADS) {
+    const int jj = w >> 4, p = w & 15;  // jj = j, j = 0..NLEV+1
+#define DX(j) S.dpo[(j) + 1][p]
+    S.ppmdx[jj][0][p] = DX(jj) / (DX(jj - 1) + DX(jj) + DX(jj + 1));
+    S.ppmdx[jj][1][p] = (2. * DX(jj - 1) + DX(jj)) / (DX(jj + 1) + DX(jj));
+    S.ppmdx[jj][2][p] = (DX(jj) + 2. * DX(jj + 1)) / (DX(jj - 1) + DX(jj));
+    if (jj <= NLEV) {
+      S.ppmdx[jj][3][p] = DX(jj) / (DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][4][p] = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
+      S.ppmdx[jj][5][p] = (2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][6][p] = (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][7][p] = (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj));
+      S.ppmdx[jj][8][p] = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][9][p] = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
+    }
+#undef DX
+  }
+  __syncthreads();
+  // ---- phase 2: data part (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209)
+  const int p = tid & 15;
+  for (int q = tid >> 4; q < qsize; q += REMAP_THREADS / 16) {
+    double* col = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
+    int R = 0;                                   // highest cell fetched so far (ghost cells continue past NLEV)
+    double pm1 = 0, pa1 = 0, pm2 = 0, pa2 = 0;   // the last two real cells (mass, mean) for the bottom mirror
+    auto read_next = [&](double& m, double& a) {
+      R++;
+      if (R <= NLEV) {
+        m = col[(size_t)(R - 1) * 16];
+        a = m / S.dpo[R + 1][p];
+        pm2 = pm1; pa2 = pa1; pm1 = m; pa1 = a;
+      } else if (R == NLEV + 1) { m = pm1; a = pa1; }   // a(nlev+1) = a(nlev)
+      else { m = pm2; a = pa2; }                         // a(nlev+2) = a(nlev-1)
+    };
+    auto dma_at = [&](int j, double am, double a0_, double ap) {
+      double d[3] = {S.ppmdx[j][0][p], S.ppmdx[j][1][p], S.ppmdx[j][2][p]};
+      return ppm_dma(d, am, a0_, ap);
+    };
+    auto ai_at = [&](int j, double aj, double ajp, double dmajp, double dmaj) {
+      return aj + S.ppmdx[j][3][p] * (ajp - aj) +
+             S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (S.ppmdx[j][6][p] - S.ppmdx[j][7][p]) * (ajp - aj) -
+                                 S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
+    };
+    double m1, a1, m2, a2, m3, a3;
+    read_next(m1, a1); read_next(m2, a2); read_next(m3, a3);
+    int kk = 1;
+    double am2 = a2, am1 = a1, a0 = a1, ap1 = a2, ap2 = a3;  // a(-1)=a(2), a(0)=a(1)
+    double m0 = m1, mp1 = m2, mp2 = m3;
+    double dma_m1 = dma_at(0, am2, am1, a0), dma_0 = dma_at(1, am1, a0, ap1), dma_p1 = dma_at(2, a0, ap1, ap2);
+    double ai_m1 = ai_at(0, am1, a0, dma_0, dma_m1), ai_0 = ai_at(1, a0, ap1, dma_p1, dma_0);
+    double masso_kk = 0.0, massn1 = 0.0;
+    double c0, c1, c2;
+    auto make_coefs = [&]() {
+      double al = ai_m1, ar = ai_0;
+      if ((ar - a0) * (a0 - al) <= 0.) { al = a0; ar = a0; }
+      if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) / 6.) al = 3. * a0 - 2. * ar;
+      if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) / 6.) ar = 3. * a0 - 2. * al;
+      c0 = 1.5 * a0 - (al + ar) / 4.;
+      c1 = ar - al;
+      c2 = -6. * a0 + 3. * (al + ar);
+    };
+    make_coefs();
+    for (int k = 1; k <= NLEV; k++) {
+      const int kt = S.kid[k - 1][p];
+      while (kk < kt) {
+        masso_kk = masso_kk + m0;
+        am2 = am1; am1 = a0; a0 = ap1; ap1 = ap2; m0 = mp1; mp1 = mp2;
+        read_next(mp2, ap2);
+        kk++;
+        dma_m1 = dma_0; dma_0 = dma_p1; dma_p1 = dma_at(kk + 1, a0, ap1, ap2);
+        ai_m1 = ai_0; ai_0 = ai_at(kk, a0, ap1, dma_p1, dma_0);
+        make_coefs();
+      }
+      const double x1 = -0.5, x2 = S.z2[k - 1][p];
+      double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) / 0.2e1 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) / 0.3e1;
+      double massn2 = masso_kk + integ * S.dpo[kk + 1][p];
+      col[(size_t)(k - 1) * 16] = massn2 - massn1;
+      massn1 = massn2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Prescribed DCMIP 1-1 / 1-2 fields on the device: dcmip_123_mod.F90:85-260,262-409 evaluated
+// with zcoords=1, as dcmip_wrapper_mod.F90:49-243 drives them.
+struct DcmipPt { double u, v, w, p, rho, q[4]; };
+__device__ inline DcmipPt dcmip_point(int test, double time, double lon, double lat, double z) {
+  const double a = 6.376e6, pi = 3.141592653589793238462643383279, Rd = 287.04, g = 9.80616, T0 = 300.0, P0 = 100000.0;
+  const double H = Rd * T0 / g;
+  DcmipPt r;
+  double p = P0 * exp(-z / H);
+  if (test == 1) {
+    const double tau = 12.0 * 86400.0, u0 = (2.0 * pi * a) / tau, k0 = (10.0 * a) / tau, omega0 = (23000.0 * pi) / tau;
+    const double RR = 0.5, ZZ = 1000.0, z0 = 5000.0, lambda0 = 5.0 * pi / 6.0, lambda1 = 7.0 * pi / 6.0;
+    double ptop = P0 * exp(-12000.0 / H);
+    double lonp = lon - 2.0 * pi * time / tau;
+    double plim = fmax(p, ptop);
+    double bs = (double)0.2f;
+    double s = 1.0 + exp((ptop - P0) / (bs * ptop)) - exp((plim - P0) / (bs * ptop)) - exp((ptop - plim) / (bs * ptop));
+    double cl = cos(lat);
+    double ud = (omega0 * a) / (bs * ptop) * cos(lonp) * (cl * cl) * cos(2.0 * pi * time / tau) *
+                (-exp((plim - P0) / (bs * ptop)) + exp((ptop - plim) / (bs * ptop)));
+    r.u = k0 * sin(lonp) * sin(lonp) * sin(2.0 * lat) * cos(pi * time / tau) + u0 * cos(lat) + ud;
+    r.v = k0 * sin(2.0 * lonp) * cos(lat) * cos(pi * time / tau);
+    r.w = -((Rd * T0) / (g * plim)) * omega0 * sin(lonp) * cos(lat) * cos(2.0 * pi * time / tau) * s;
+    r.rho = p / (Rd * T0);
+    double sin_tmp = sin(lat) * sin(0.0), cos_tmp = cos(lat) * cos(0.0);
+    double rr1 = acos(sin_tmp + cos_tmp * cos(lon - lambda0));
+    double rr2 = acos(sin_tmp + cos_tmp * cos(lon - lambda1));
+    double hz = (z - z0) / ZZ;
+    double d1 = fmin(1.0, (rr1 / RR) * (rr1 / RR) + hz * hz), d2 = fmin(1.0, (rr2 / RR) * (rr2 / RR) + hz * hz);
+    r.q[0] = 0.5 * (1.0 + cos(pi * d1)) + 0.5 * (1.0 + cos(pi * d2));
+    r.q[1] = 0.9 - 0.8 * (r.q[0] * r.q[0]);
+    r.q[2] = (d1 <= RR || d2 <= RR) ? 1.0 : 0.1;
+    if (z > z0 && fabs(lat) < 0.125) r.q[2] = 0.1;
+    r.q[3] = 1.0 - 0.3 * (r.q[0] + r.q[1] + r.q[2]);
+  } else {
+    const double tau = 86400.0, u0 = 40.0, w0 = 0.15, K = 5.0, z1 = 2000.0, z2 = 5000.0, z0 = 0.5 * (z1 + z2), ztop = 12000.0;
+    double ptop = P0 * exp(-ztop / H);
+    double rho = fmax(p, ptop) / (Rd * T0), rho0 = P0 / (Rd * T0);
+    r.u = u0 * cos(lat);
+    double hstar = fmin(z / ztop, 1.0);
+    r.v = -(rho0 / rho) * (a * w0 * pi) / (K * ztop) * cos(lat) * sin(K * lat) * cos(pi * hstar) * cos(pi * time / tau);
+    r.w = (rho0 / rho) * (w0 / K) * (-2.0 * sin(K * lat) * sin(lat) + K * cos(lat) * cos(K * lat)) * sin(pi * hstar) * cos(pi * time / tau);
+    r.rho = rho;
+    r.q[0] = 0.0;
+    r.q[1] = (z < z2 && z > z1) ? 0.5 * (1.0 + cos(2.0 * pi * (z - z0) / (z2 - z1))) : 0.0;
+    r.q[2] = 0.0; r.q[3] = 0.0;
+  }
+  r.p = p;
+  return r;
+}
+
+// per-step inputs: derived%dp, vn0 = u(t_wind)*dp, eta_dot_dpdn(t_now), omega_p = 0
+// zm[72], zi[73], pint[73] are per-level constants prepared on the host (dcmip_wrapper_mod.F90:68-89,183)
+__global__ void k_dcmip_step(int nelemd, int test, double t_wind, double t_now, const double* __restrict__ lat,
+                             const double* __restrict__ lon, const double* __restrict__ zm, const double* __restrict__ zi,
+                             const double* __restrict__ pint, double* __restrict__ vn0, double* __restrict__ dp,
+                             double* __restrict__ eta, double* __restrict__ omega_p) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)nelemd * NLEVP * 16) return;
+  const int p = (int)(t & 15), k = (int)((t >> 4) % NLEVP), e = (int)(t / (NLEVP * 16));
+  const double lo = lon[(size_t)e * 16 + p], la = lat[(size_t)e * 16 + p];
+  DcmipPt r = dcmip_point(test, t_now, lo, la, zi[k]);
+  eta[((size_t)e * NLEVP + k) * 16 + p] = -9.80616 * r.rho * r.w;
+  if (k < NLEV) {
+    DcmipPt m = dcmip_point(test, t_wind, lo, la, zm[k]);
+    double dpr = pint[k + 1] - pint[k];
+    size_t o = ((size_t)e * NLEV + k) * 16 + p;
+    dp[o] = dpr;
+    vn0[(((size_t)e * NLEV + k) * 2 + 0) * 16 + p] = m.u * dpr;
+    vn0[(((size_t)e * NLEV + k) * 2 + 1) * 16 + p] = m.v * dpr;
+    omega_p[o] = 0.0;
+  }
+}
+
+// initial tracers: Qdp(:,:,:,q,1:2) = Q*dp(hyai,hybi,ps_v=p0) (prim_driver_mod.F90:646-669); checkerboard for the extra
+// tracers (dcmip_wrapper_mod.F90:215-243)
+__global__ void k_dcmip_init(int nelemd, int qsize, int test, const double* __restrict__ lat, const double* __restrict__ lon,
+                             const double* __restrict__ zm, const double* __restrict__ pint, const double* __restrict__ dph,
+                             double* __restrict__ qdp0, double* __restrict__ qdp1, double* __restrict__ dp3d,
+                             double* __restrict__ ps_v) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)nelemd * NLEV * 16) return;
+  const int p = (int)(t & 15), k = (int)((t >> 4) % NLEV), e = (int)(t / (NLEV * 16));
+  const double lo = lon[(size_t)e * 16 + p], la = lat[(size_t)e * 16 + p];
+  DcmipPt m = dcmip_point(test, 0.0, lo, la, zm[k]);
+  double term = sin(9. * lo) * sin(9. * la);
+  double checker = term < 0. ? 0.0 : 1.0;
+  for (int q = 0; q < qsize; q++) {
+    double Q = test == 1 ? (q < 4 ? m.q[q] : checker) : (q == 1 ? m.q[1] : checker);
+    size_t o = (((size_t)e * qsize + q) * NLEV + k) * 16 + p;
+    qdp0[o] = Q * dph[k];
+    qdp1[o] = Q * dph[k];
+  }
+  dp3d[((size_t)e * NLEV + k) * 16 + p] = pint[k + 1] - pint[k];
+  if (k == 0) ps_v[(size_t)e * 16 + p] = pint[NLEV];
+}
+
+}  // namespace tse

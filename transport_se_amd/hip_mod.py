@@ -1,0 +1,189 @@
+"""hip_mod -- Python mirror of the Fortran host seam.
+
+The reference plugs its accelerator path in through `cuda_mod` (src/share/cuda_mod.F90:57-64):
+    cuda_mod_init(elem,hybrid,deriv,hvcoord), copy_qdp_h2d(elem,nt), copy_qdp_d2h(elem,nt),
+    euler_step_cuda(np1_qdp,n0_qdp,dt,elem,...,DSSopt,rhs_multiplier), qdp_time_avg_cuda(...), vertical_remap_cuda(...)
+`HipMod` exposes the same operations with the same argument meaning over the C ABI of
+include/transport_se_hip.h; `transport_se_amd/fortran/hip_mod.F90` is the ISO_C_BINDING twin a Fortran host uses.
+
+`elem` here is a dict of dense numpy arrays holding the element_t fields the path touches, in the reference's
+own index order reversed to C order (element index first):
+    Qdp[ie][tl][q][k][j][i]  (state%Qdp(np,np,nlev,qsize_d,2)),  vn0[ie][k][c][j][i], dp/divdp/divdp_proj/omega_p[ie][k][j][i],
+    eta_dot_dpdn[ie][nlevp][j][i], Dinv[ie][j][i][b][a], metdet/rmetdet/spheremp/rspheremp[ie][j][i],
+    putmapP/getmapP/reverse[ie][8]
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+NP, NLEV, NLEVP = 4, 72, 73
+DSSeta, DSSomega, DSSdiv_vdp_ave = 1, 2, 3  # prim_advection_mod.F90:454-456
+
+
+class TseError(RuntimeError):
+    """what the Fortran side turns into abortmp(msg) (parallel_mod.F90:274-287)"""
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class HipMod:
+    def __init__(self, elem, deriv_Dvv, hvcoord, qsize, nu_q, limiter_option=8, rsplit=3, device=-1,
+                 schedule=None, exchange=None):
+        """cuda_mod_init.  hvcoord = (hyai, hybi, ps0).  schedule = dict(send=[(peer, ptrP, lengthP)...],
+        recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr) -> 0."""
+        L = _lib.lib()
+        self.L = L
+        self.qsize = int(qsize)
+        self.nelemd = int(elem["metdet"].shape[0])
+        self._keep = []
+        a = _lib.InitArgs()
+        a.nelemd, a.qsize, a.device, a.nu_q = self.nelemd, self.qsize, device, float(nu_q)
+        a.limiter_option, a.rsplit = int(limiter_option), int(rsplit)
+
+        def keep(x, dtype):
+            x = np.ascontiguousarray(x, dtype=dtype); self._keep.append(x); return x
+        hyai, hybi, ps0 = hvcoord
+        a.Dvv = _vp(keep(deriv_Dvv, np.float64)); a.hyai = _vp(keep(hyai, np.float64)); a.hybi = _vp(keep(hybi, np.float64))
+        a.ps0 = float(ps0)
+        for name, cnt in (("Dinv", 64), ("metdet", 16), ("rmetdet", 16), ("spheremp", 16), ("rspheremp", 16)):
+            arr = keep(elem[name], np.float64)
+            assert arr.size == self.nelemd * cnt, name
+            setattr(a, name, _vp(arr)); setattr(a, name + "_stride", cnt * 8)
+        a.putmapP = _vp(keep(elem["putmapP"], np.int32)); a.getmapP = _vp(keep(elem["getmapP"], np.int32))
+        a.reverse = _vp(keep(elem["reverse"], np.int32))
+        sched = schedule or dict(send=[], recv=[])
+        for side in ("send", "recv"):
+            cyc = np.array(sched[side], dtype=np.int32).reshape(-1, 3)
+            setattr(a, "n" + side, cyc.shape[0])
+            for col, nm in enumerate(("peer", "ptrP", "lengthP")):
+                setattr(a, "%s_%s" % (side, nm), _vp(keep(cyc[:, col], np.int32)))
+        self.schedule = sched
+        if exchange is not None:
+            def _cb(user, sbuf, rbuf, nlyr):
+                try:
+                    return int(exchange(sbuf, rbuf, nlyr) or 0)
+                except Exception as ex:  # noqa: BLE001
+                    print("exchange callback failed:", ex)
+                    return 1
+            self._cb = _lib.EXCHANGE_FN(_cb)
+            a.exchange = self._cb
+        h = C.c_void_p()
+        self._chk(L.tse_init(C.byref(h), C.byref(a)))
+        self.h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise TseError(self.L.tse_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tse_finalize(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- copy_qdp_h2d / copy_qdp_d2h (cuda_mod.F90:429-469) ----
+    def copy_qdp_h2d(self, elem, nt):
+        q = elem["Qdp"]; assert q.dtype == np.float64 and q.flags.c_contiguous
+        self._chk(self.L.tse_copy_qdp_h2d(self.h, _vp(q), q.strides[0], q.shape[2], nt))
+
+    def copy_qdp_d2h(self, elem, nt):
+        q = elem["Qdp"]; assert q.dtype == np.float64 and q.flags.c_contiguous
+        self._chk(self.L.tse_copy_qdp_d2h(self.h, _vp(q), q.strides[0], q.shape[2], nt))
+
+    # ---- per-step derived inputs/outputs (what euler_step_cuda stages from elem%derived, cuda_mod.F90:535-547) ----
+    def set_derived(self, elem):
+        def arg(name):
+            x = elem.get(name)
+            if x is None:
+                return None, 0
+            assert x.dtype == np.float64 and x.flags.c_contiguous
+            return _vp(x), x.strides[0]
+        v, sv = arg("vn0"); d, sd = arg("dp"); e, se = arg("eta_dot_dpdn"); o, so = arg("omega_p")
+        self._chk(self.L.tse_set_derived(self.h, v, sv, d, sd, e, se, o, so))
+
+    def get_derived(self, elem):
+        args = []
+        for name in ("divdp_proj", "eta_dot_dpdn", "omega_p", "divdp", "dp3d", "ps_v"):
+            x = elem.get(name)
+            args += [_vp(x), x.strides[0]] if x is not None else [None, 0]
+        self._chk(self.L.tse_get_derived(self.h, *args))
+
+    # ---- the path ----
+    def compute_divdp(self):
+        self._chk(self.L.tse_compute_divdp(self.h))
+
+    def euler_step(self, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier):
+        self._chk(self.L.tse_euler_step(self.h, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier))
+
+    def qdp_time_avg(self, rkstage, n0_qdp, np1_qdp):
+        self._chk(self.L.tse_qdp_time_avg(self.h, rkstage, n0_qdp, np1_qdp))
+
+    def advec_tracers_remap_rk2(self, dt, n0_qdp, np1_qdp):
+        self._chk(self.L.tse_advec_tracers_remap_rk2(self.h, dt, n0_qdp, np1_qdp))
+
+    def vertical_remap(self, dt, np1_qdp):
+        self._chk(self.L.tse_vertical_remap(self.h, dt, np1_qdp))
+
+    def get_qminmax(self):
+        qmin = np.empty((self.nelemd, self.qsize, NLEV)); qmax = np.empty_like(qmin)
+        self._chk(self.L.tse_get_qminmax(self.h, _vp(qmin), _vp(qmax)))
+        return qmin, qmax
+
+    # ---- prescribed fields / device-resident loop ----
+    def dcmip_init(self, test_case, lat, lon, hyam, hybm):
+        self._chk(self.L.tse_dcmip_init(self.h, test_case, _vp(np.ascontiguousarray(lat, np.float64)),
+                                        _vp(np.ascontiguousarray(lon, np.float64)),
+                                        _vp(np.ascontiguousarray(hyam, np.float64)), _vp(np.ascontiguousarray(hybm, np.float64))))
+
+    def dcmip_set_initial(self):
+        self._chk(self.L.tse_dcmip_set_initial(self.h))
+
+    def dcmip_step_inputs(self, nstep, tstep):
+        self._chk(self.L.tse_dcmip_step_inputs(self.h, nstep, tstep))
+
+    def prim_run_subcycle(self, tstep, nsub, nstep):
+        ns = C.c_int(nstep)
+        self._chk(self.L.tse_prim_run_subcycle(self.h, tstep, nsub, C.byref(ns)))
+        return ns.value
+
+    def synchronize(self):
+        self._chk(self.L.tse_synchronize(self.h))
+
+    # ---- introspection ----
+    def device_ptr(self, name):
+        n = C.c_size_t()
+        p = self.L.tse_device_ptr(self.h, name.encode(), C.byref(n))
+        return p, n.value
+
+    def timing(self, enable=True):
+        self.L.tse_timing(self.h, int(enable))
+
+    def kernel_time(self, name):
+        ms = C.c_double(); n = C.c_long()
+        self.L.tse_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
+    def halo_layout(self):
+        a, b = C.c_int(), C.c_int()
+        self.L.tse_halo_layout(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def fetch(self, name, shape):
+        """debug/test helper: copy an internal device array to the host (hipMemcpy through torch-free ctypes)"""
+        p, nbytes = self.device_ptr(name)
+        out = np.empty(shape, dtype=np.float64)
+        assert out.nbytes <= nbytes, (name, out.nbytes, nbytes)
+        self.synchronize()
+        hip = C.CDLL("libamdhip64.so")
+        rc = hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(p), C.c_size_t(out.nbytes), C.c_int(2))
+        if rc:
+            raise TseError("hipMemcpy D2H failed: %d" % rc)
+        return out
