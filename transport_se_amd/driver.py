@@ -1,0 +1,104 @@
+"""prim_run driver: the reference's time loop around the tracer path, device-resident.
+
+Mirrors prim_run_subcycle / prim_step (reference src/share/prim_driver_mod.F90:701-943) and TimeLevel_Qdp
+(time_mod.F90:85-109): rsplit tracer steps, each preceded by the prescribed-field refresh of prim_advance_exp
+(prim_advance_mod.F90:110-149), then vertical_remap.  One process per GPU; for world_size > 1 the elements are
+cut into contiguous chunks of the global element order and the DSS halo goes through torch.distributed
+(backend nccl == RCCL over xGMI) inside the exchange callback of the C ABI (the bndry_exchangeV seam).
+"""
+import numpy as np
+
+from . import cube_mesh as cm
+from .hip_mod import HipMod
+from .hybvcoord import HvCoord
+
+NU_Q = {8: 6e16, 30: 1e15, 120: 1e13}     # test/run_ne8_tests.sh:27, run_ne30_tests.sh, run_ne120_perf.sh:29
+TSTEP = {8: 400.0, 30: 300.0, 120: 75.0}  # test/run_ne8_tests.sh:25, run_ne120_perf.sh:28
+
+
+def partition(nelem, nranks):
+    """contiguous chunks; the first mod(nelem,npart) ranks take one extra (spacecurve_mod.F90:1235-1263)"""
+    base, extra = divmod(nelem, nranks)
+    sizes = np.array([base + (1 if r < extra else 0) for r in range(nranks)])
+    return np.repeat(np.arange(nranks), sizes)
+
+
+class HaloExchange:
+    """bndry_exchangeV (bndry_mod.F90:74-124) on device-resident packed slots: one isend + one irecv per
+    neighbour rank, message = nlyr * lengthP doubles, slot s at column offset sum(lengthP[:s])."""
+
+    def __init__(self, sched, device, dist_mod, torch_mod):
+        self.sched, self.dist, self.torch, self.device = sched, dist_mod, torch_mod, device
+        self.off_s = np.concatenate([[0], np.cumsum([s[2] for s in sched["send"]])]).astype(int)
+        self.off_r = np.concatenate([[0], np.cumsum([s[2] for s in sched["recv"]])]).astype(int)
+
+    def _wrap(self, ptr, count):
+        iface = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+        holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
+        return self.torch.as_tensor(holder, device=self.device)
+
+    def __call__(self, sbuf, rbuf, nlyr):
+        torch, dist = self.torch, self.dist
+        ns, nr = int(self.off_s[-1]), int(self.off_r[-1])
+        st = self._wrap(sbuf, ns * nlyr); rt = self._wrap(rbuf, nr * nlyr)
+        ops = []
+        for i, (peer, _, ln) in enumerate(self.sched["recv"]):
+            ops.append(dist.P2POp(dist.irecv, rt[self.off_r[i] * nlyr:(self.off_r[i] + ln) * nlyr], int(peer)))
+        for i, (peer, _, ln) in enumerate(self.sched["send"]):
+            ops.append(dist.P2POp(dist.isend, st[self.off_s[i] * nlyr:(self.off_s[i] + ln) * nlyr], int(peer)))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        torch.cuda.current_stream(self.device).synchronize()
+        return 0
+
+
+class PrimRun:
+    def __init__(self, ne, qsize, test_case=1, nu_q=None, tstep=None, rsplit=3, rank=0, world=1, device=0,
+                 dist_mod=None, torch_mod=None):
+        self.ne, self.qsize, self.rsplit, self.test_case = ne, qsize, rsplit, test_case
+        self.nu_q = NU_Q.get(ne, 1e15 * (30.0 / ne) ** 3.2) if nu_q is None else nu_q
+        self.tstep = TSTEP.get(ne, 300.0 * 30.0 / ne) if tstep is None else tstep
+        self.hv = HvCoord()
+        topo = cm.topology(ne)
+        geo = cm.geometry(ne, topo)
+        self.nelem = 6 * ne * ne
+        owner = partition(self.nelem, world)
+        desc = cm.edge_descriptors(topo, owner, rank)
+        mine = desc["elems"]
+        self.mine = mine
+        self.elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine],
+                         spheremp=geo["spheremp"][mine], rspheremp=geo["rspheremp"][mine],
+                         putmapP=desc["putmapP"], getmapP=desc["getmapP"], reverse=desc["reverse"])
+        self.lat, self.lon = geo["lat"][mine], geo["lon"][mine]
+        exchange = None
+        if world > 1:
+            exchange = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod)
+        self.hip = HipMod(self.elem, cm.dvv(), (self.hv.hyai, self.hv.hybi, self.hv.ps0), qsize, self.nu_q,
+                          rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=exchange)
+        self.hip.dcmip_init(test_case, self.lat, self.lon, self.hv.hyam, self.hv.hybm)
+        self.hip.dcmip_set_initial()
+        self.nstep = 0
+
+    def step(self):
+        """one prim_step (+ vertical_remap when it closes an rsplit cycle)"""
+        hip = self.hip
+        hip.dcmip_step_inputs(self.nstep, self.tstep)
+        n0 = 1 if self.nstep % 2 == 0 else 2
+        hip.advec_tracers_remap_rk2(self.tstep, n0, 3 - n0)
+        self.nstep += 1
+        if self.nstep % self.rsplit == 0:
+            hip.vertical_remap(self.tstep * self.rsplit, 3 - n0)
+        return 3 - n0
+
+    def run(self, nsteps):
+        np1 = 2
+        for _ in range(nsteps):
+            np1 = self.step()
+        return np1
+
+    def fetch_qdp(self, tl):
+        n, q = self.mine.size, self.qsize
+        return self.hip.fetch("qdp", (2, n, q, 72, 4, 4))[tl - 1]
+
+    def close(self):
+        self.hip.close()
