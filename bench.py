@@ -41,7 +41,9 @@ def cpu_baseline(qsize, seconds_hint=20.0):
             out = tempfile.mkdtemp(prefix="tse_cpu_")
             stdin = "%d %d %d %r %r 1 -1\n'%s'\n'%s'\n" % (ne, qsize, nsteps, 300.0, 7e15, out, vdir)
             env = dict(os.environ); env.pop("HIP_VISIBLE_DEVICES", None)
-            res = subprocess.run(["/opt/conda/bin/mpiexec", "-n", str(cores), harness], input=stdin.encode(),
+            # the reference keeps Qtens_biharmonic(np,np,nlev,qsize,nets:nete) on the stack (prim_advection_mod.F90:708)
+            cmd = "ulimit -s unlimited 2>/dev/null || ulimit -s $(ulimit -H -s); exec /opt/conda/bin/mpiexec -n %d %s" % (cores, harness)
+            res = subprocess.run(["bash", "-c", cmd], input=stdin.encode(),
                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
             for line in res.stdout.decode().splitlines():
                 if "tracer-DOF-steps/s" in line:

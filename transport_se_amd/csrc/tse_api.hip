@@ -388,10 +388,10 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     Scope s(c, "dss");
     const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
     if (Qn0_avg)
-      hipLaunchKernelGGL(k_dss<1>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
+      hipLaunchKernelGGL(k_dss<1>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
                          Qn0_avg, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
     else
-      hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
+      hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
                          (const double*)nullptr, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
     LAUNCH_CHECK();
   }
@@ -400,7 +400,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     const int nchunk = (NLEV + DSS_LAYERS - 1) / DSS_LAYERS;
     // out of place (the source must stay intact while neighbours read it): write a scratch level buffer, copy back
     double* outbuf = c->lvl_tmp2;
-    hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, NLEV, nchunk, c->dss_tab, c->rspheremp, var_src,
+    hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, NLEV, nchunk, c->dss_tab, c->rspheremp, var_src,
                        outbuf, (const double*)nullptr, c->recvbuf, nq + NLEV, nq, c->spheremp);
     LAUNCH_CHECK();
     if (var_levels == NLEV) HIPCHK(hipMemcpyAsync(var, outbuf, c->lev() * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -454,7 +454,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     {
       Scope s(c, "dss");
       const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
-      hipLaunchKernelGGL(k_dss<0>, dim3(c->nelemd * nchunk), dim3(DSS_THREADS), 0, c->stream, nq, nchunk, c->dss_tab, c->rspheremp, c->B, c->T,
+      hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, c->B, c->T,
                          (const double*)nullptr, c->recvbuf, nq, 0, (const double*)nullptr);
       LAUNCH_CHECK();
     }

@@ -102,54 +102,102 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0) {
   const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
-  RowGeo g;
-  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
-  const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
-  double dpk[4], vs1[4], vs2[4], dps[4], c[4], t0[4], t1[4];
-  load4(dp + lo, dpk); load4(divdp_proj + lo, t0); load4(divdp + lo, t1);
+  // per-(e,k,row) constants, computed once and reused for every tracer:
+  //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
+  //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
+  double a1[4], a2[4], rm[4], dps[4], rdps[4], c[4], spm[4], rdpk[4], dcol[4];
+  RowGeo* gl = nullptr;  // the full metric row is only needed for the Laplacian of stage 3
+  RowGeo gfull;
+  {
+    RowGeo g;
+    load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+    const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
+    double dpk[4], vs1[4], vs2[4], t0[4], t1[4];
+    load4(dp + lo, dpk); load4(divdp_proj + lo, t0); load4(divdp + lo, t1);
+    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
+    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
 #pragma unroll
-  for (int i = 0; i < 4; i++) { dpk[i] = dpk[i] - RHS * dt * t0[i]; dps[i] = dpk[i] - dt * t1[i]; }
-  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
-  load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
-#pragma unroll
-  for (int i = 0; i < 4; i++) { vs1[i] = vs1[i] / dpk[i]; vs2[i] = vs2[i] / dpk[i]; c[i] = g.spheremp[i] * dps[i]; }
+    for (int i = 0; i < 4; i++) {
+      dpk[i] = dpk[i] - RHS * dt * t0[i];
+      dps[i] = dpk[i] - dt * t1[i];
+      rdps[i] = 1.0 / dps[i];
+      rdpk[i] = 1.0 / dpk[i];
+      double u1 = vs1[i] * rdpk[i], u2 = vs2[i] * rdpk[i];   // Vstar = vn0/dp
+      a1[i] = g.metdet[i] * (g.Di11[i] * u1 + g.Di12[i] * u2);
+      a2[i] = g.metdet[i] * (g.Di21[i] * u1 + g.Di22[i] * u2);
+      rm[i] = dt * (g.rmetdet[i] * RREARTH);
+      spm[i] = g.spheremp[i];
+      c[i] = spm[i] * dps[i];
+      dcol[i] = g.dcol[i];
+    }
+    if (RHS == 2) { gfull = g; gl = &gfull; }
+  }
   const double sumc = quad_sum(((c[0] + c[1]) + c[2]) + c[3]);
-  const double visc = RHS == 2 ? -3.0 * dt * nu_q * dp0[kc] : 0.0;  // -rhs_viss*dt*nu_q*dp0
+  double visc[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) visc[i] = RHS == 2 ? (-3.0 * dt * nu_q * dp0[kc]) / spm[i] : 0.0;  // -rhs_viss*dt*nu_q*dp0/spheremp
 
+  const size_t qstride = (size_t)NLEV * 16;
+  size_t so = ((size_t)e * qsize * NLEV + kc) * 16 + j * 4;
+  size_t mi = (size_t)e * qsize * NLEV + kc;
+  double qn[4], ls[4], minp, maxp;
+  load4(Qn0 + so, qn);
+  if (RHS == 2) load4(lap + so, ls);
+  minp = qmin[mi]; maxp = qmax[mi];
   for (int q = 0; q < qsize; q++) {
-    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
-    const size_t mi = ((size_t)e * qsize + q) * NLEV + kc;
-    double qn[4], g1[4], g2[4], div[4], x[4];
-    load4(Qn0 + so, qn);
-    double minp = qmin[mi], maxp = qmax[mi];
+    // software prefetch of the next tracer's slab row + bounds (vmcnt is in-order: issue everything for q+1 first)
+    double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0, maxx = 0;
+    if (q + 1 < qsize) {
+      load4(Qn0 + so + qstride, qnx);
+      if (RHS == 2) load4(lap + so + qstride, lsx);
+      minx = qmin[mi + NLEV]; maxx = qmax[mi + NLEV];
+    }
+    double gv1[4], gv2[4], x[4], dx[4], dy[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { g1[i] = vs1[i] * qn[i]; g2[i] = vs2[i] * qn[i]; }
-    divergence_sphere_row(D, g, g1, g2, div);
+    for (int i = 0; i < 4; i++) { gv1[i] = a1[i] * qn[i]; gv2[i] = a2[i] * qn[i]; }
+    // d/dx in-register, d/dy across the quad (deriv_xy with the lane's dcol)
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = qn[i] - dt * div[i];
+    for (int l = 0; l < 4; l++) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = 0; i < 4; i++) s = s + D.d[l * 4 + i] * gv1[i];
+      dx[l] = s;
+    }
+    {
+      double r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        r0[i] = quad_bcast<0>(gv2[i]); r1[i] = quad_bcast<1>(gv2[i]); r2[i] = quad_bcast<2>(gv2[i]); r3[i] = quad_bcast<3>(gv2[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) dy[i] = ((dcol[0] * r0[i] + dcol[1] * r1[i]) + dcol[2] * r2[i]) + dcol[3] * r3[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
     if (RHS == 1) {
-      double qq[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) qq[i] = qn[i] / dpk[i];
-      minp = fmin(minp, quad_min(fmin(fmin(qq[0], qq[1]), fmin(qq[2], qq[3]))));
-      maxp = fmax(maxp, quad_max(fmax(fmax(qq[0], qq[1]), fmax(qq[2], qq[3]))));
+      double q0 = qn[0] * rdpk[0], q1 = qn[1] * rdpk[1], q2 = qn[2] * rdpk[2], q3 = qn[3] * rdpk[3];
+      minp = fmin(minp, quad_min(fmin(fmin(q0, q1), fmin(q2, q3))));
+      maxp = fmax(maxp, quad_max(fmax(fmax(q0, q1), fmax(q2, q3))));
     }
     if (RHS == 2) {
-      double s[4], l2[4];
-      load4(lap + so, s);
-      laplace_sphere_wk_row(D, g, s, l2);
+      double l2[4];
+      laplace_sphere_wk_row(D, *gl, ls, l2);
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = x[i] + visc * l2[i] / g.spheremp[i];
+      for (int i = 0; i < 4; i++) x[i] = x[i] + visc[i] * l2[i];
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = x[i] / dps[i];
+    for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
     limiter8_quad(x, c, sumc, minp, maxp);
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = g.spheremp[i] * (x[i] * dps[i]);
+    for (int i = 0; i < 4; i++) x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
     if (k < NLEV) {
       store4(Tout + so, x);
       if (j == 0) { qmin[mi] = minp; qmax[mi] = maxp; }
     }
+#pragma unroll
+    for (int i = 0; i < 4; i++) { qn[i] = qnx[i]; ls[i] = lsx[i]; }
+    minp = minx; maxp = maxx;
+    so += qstride; mi += NLEV;
   }
 }
 
@@ -195,12 +243,18 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_lap1(Dvv_t D, GeoPtrs G, int q
 constexpr int DSS_THREADS = 256;
 constexpr int DSS_LAYERS = DSS_THREADS / 4;
 template <int MODE>
-__global__ __launch_bounds__(DSS_THREADS) void k_dss(int nlyr, int nchunk, const int2* __restrict__ tab,
+__global__ __launch_bounds__(DSS_THREADS) void k_dss(int nelemd, int nlyr, int nchunk, const int2* __restrict__ tab,
                                                      const double* __restrict__ rspheremp, const double* __restrict__ src,
                                                      double* __restrict__ dst, const double* __restrict__ Qn0,
                                                      const double* __restrict__ recvbuf, int nlyr_halo, int lyr0,
                                                      const double* __restrict__ scale_in /* spheremp or null */) {
-  const int e = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  // work item (chunk, e), chunk-major; the 8 XCDs (blockIdx % 8 shares an XCD, blocks dealt round-robin) each walk a
+  // contiguous range of elements, so that the blocks resident on one XCD at a time cover a compact band of
+  // neighbouring elements of ONE layer chunk and the neighbour-edge gathers hit that XCD's L2
+  const int S8 = (nelemd + 7) >> 3;
+  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
+  const int e = xcd * S8 + it % S8, chunk = it / S8;
+  if (e >= nelemd) return;
   const int tid = threadIdx.x, j = tid & 3;
   int l = chunk * DSS_LAYERS + (tid >> 2);
   const bool active = l < nlyr;
