@@ -86,6 +86,9 @@ int tse_copy_qdp_d2h(tse_ctx *ctx, double *qdp_elem1, size_t elem_stride, int qs
  * NULL pointers are skipped. */
 int tse_set_derived(tse_ctx *ctx, const double *vn0, size_t vn0_stride, const double *dp, size_t dp_stride,
                     const double *eta_dot_dpdn, size_t eta_stride, const double *omega_p, size_t omega_stride);
+/* derived%divdp / derived%divdp_proj as the host computed them (Prim_Advec_Tracers_remap_rk2 does this outside the
+ * hooked routines, prim_advection_mod.F90:614-623); tse_compute_divdp is the on-device equivalent. */
+int tse_set_divdp(tse_ctx *ctx, const double *divdp, size_t s0, const double *divdp_proj, size_t s1);
 /* outputs the path writes back into elem: derived%divdp_proj, derived%eta_dot_dpdn (DSS'd, levels 1:nlev),
  * derived%omega_p (DSS'd), derived%divdp, state%dp3d(:,:,:,np1), state%ps_v(:,:,np1).  NULL pointers are skipped. */
 int tse_get_derived(tse_ctx *ctx, double *divdp_proj, size_t s1, double *eta_dot_dpdn, size_t s2, double *omega_p, size_t s3,

@@ -1,0 +1,41 @@
+"""-m gpu: the drop-in boundary exercised from the reference's own language.
+
+transport_se_amd/fortran/_build/hip_harness is the reference's UNMODIFIED prim_advection_mod.F90 compiled with
+-DUSE_CUDA_FORTRAN=1 and linked against transport_se_amd/fortran/cuda_mod_hip.F90 (a Fortran module named `cuda_mod`
+bound to libtransport_se_hip.so with ISO_C_BINDING): the reference's own `call euler_step_cuda(...)`,
+`call qdp_time_avg_cuda(...)`, `call vertical_remap_cuda(...)` hooks run on the MI355X.  Its output must equal the
+plain-Fortran reference's (tests/golden/ref_ne2_dcmip11.npz) to the step tolerance.  Built in the build container
+(needs /root/reference + amdflang); the binary travels to the GPU box like the .so."""
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HARNESS = os.path.join(ROOT, "transport_se_amd", "fortran", "_build", "hip_harness")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(MPIEXEC)), reason="Fortran drop-in harness not built")
+def test_reference_hooks_drive_the_hip_library(gold):
+    g = gold("ref_ne2_dcmip11.npz")
+    cfg = json.loads(str(g["config"]))
+    out = tempfile.mkdtemp(prefix="tse_f90_")
+    stdin = "%d %d %d %r %r %d 1\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
+                                                 out, os.path.join(ROOT, "tests", "golden", "vcoord"))
+    res = subprocess.run([MPIEXEC, "-n", "1", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    log = res.stdout.decode()
+    assert "ref_harness done" in log, log[-2000:]
+    for tag, key in (("000001", "qdp_step1"), ("000003", "qdp_step3"), ("000006", "qdp_step6")):
+        st = po.read_state(os.path.join(out, "state_%s_r0000.bin" % tag))
+        err = np.abs(st["qdp"] - g[key]).max() / np.abs(g[key]).max()
+        assert err < 5e-12, (tag, err)
+    s3 = po.read_state(os.path.join(out, "state_000003_r0000.bin"))
+    assert np.abs(s3["dp3d"] - g["dp3d_step3"]).max() / np.abs(g["dp3d_step3"]).max() < 1e-13
+    assert np.abs(s3["ps_v"] - g["ps_v_step3"]).max() / 1e5 < 1e-13

@@ -42,7 +42,7 @@ _lib = None
 
 # every symbol include/transport_se_hip.h declares
 SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse_copy_qdp_h2d", "tse_copy_qdp_d2h",
-           "tse_set_derived", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
+           "tse_set_derived", "tse_set_divdp", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
            "tse_halo_layout"]
@@ -65,6 +65,7 @@ def lib():
     L.tse_copy_qdp_h2d.argtypes = [vp, vp, sz, i, i]
     L.tse_copy_qdp_d2h.argtypes = [vp, vp, sz, i, i]
     L.tse_set_derived.argtypes = [vp, vp, sz, vp, sz, vp, sz, vp, sz]
+    L.tse_set_divdp.argtypes = [vp, vp, sz, vp, sz]
     L.tse_get_derived.argtypes = [vp] + [vp, sz] * 6
     L.tse_advec_tracers_remap_rk2.argtypes = [vp, d, i, i]
     L.tse_compute_divdp.argtypes = [vp]

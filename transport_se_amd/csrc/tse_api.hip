@@ -307,6 +307,11 @@ int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, 
   if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
   return 0;
 }
+int tse_set_divdp(tse_ctx* c, const double* divdp, size_t s0, const double* divdp_proj, size_t s1) {
+  if (put_level(c, c->divdp, divdp, s0, NLEV * 16, NLEV * 16)) return 1;
+  if (put_level(c, c->divdp_proj, divdp_proj, s1, NLEV * 16, NLEV * 16)) return 1;
+  return 0;
+}
 int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size_t s2, double* omega_p, size_t s3, double* divdp,
                     size_t s4, double* dp3d, size_t s5, double* ps_v, size_t s6) {
   if (get_level(c, c->divdp_proj, divdp_proj, s1, NLEV * 16, NLEV * 16)) return 1;

@@ -1,0 +1,217 @@
+! cuda_mod_hip.F90 -- the Fortran half of the drop-in boundary.
+!
+! Provides a module named `cuda_mod` with the public names the reference's accelerator seam expects
+! (reference src/share/cuda_mod.F90:57-64), implemented over the C ABI of include/transport_se_hip.h with
+! ISO_C_BINDING.  Compiling the reference's prim_advection_mod.F90 with -DUSE_CUDA_FORTRAN=1 against THIS module
+! makes its own hooks
+!     euler_step      -> call euler_step_cuda(np1_qdp,n0_qdp,dt,elem,hvcoord,hybrid,deriv,nets,nete,DSSopt,rhs_multiplier)
+!                                                                      (prim_advection_mod.F90:715-718)
+!     qdp_time_avg    -> call qdp_time_avg_cuda(elem,rkstage,n0_qdp,np1_qdp,limiter_option,0d0,nets,nete)   (:653-656)
+!     vertical_remap  -> call vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,nets,nete)                    (:1279-1282)
+! land in the HIP library; the driver calls cuda_mod_init / copy_qdp_h2d / copy_qdp_d2h exactly where
+! prim_driver_mod.F90:686-689,726-728,781-784,798-801 does.  Host code stays Fortran; elem(:) stays the host copy.
+! One MPI rank drives one GPU; all OpenMP threads must reach these calls with nets:nete covering 1:nelemd
+! (NThreads=1), as the CUDA seam's master-only sections assume (cuda_mod.F90:6-8).
+module cuda_mod
+  use iso_c_binding
+  use kinds,          only : real_kind
+  use dimensions_mod, only : np, nlev, nlevp, nelemd, qsize, qsize_d
+  use element_mod,    only : element_t
+  use derivative_mod, only : derivative_t
+  use hybvcoord_mod,  only : hvcoord_t
+  use hybrid_mod,     only : hybrid_t
+  use parallel_mod,   only : abortmp
+  use control_mod,    only : nu_q, limiter_option, rsplit
+  use schedtype_mod,  only : schedule
+  implicit none
+  private
+  public :: cuda_mod_init, euler_step_cuda, qdp_time_avg_cuda, vertical_remap_cuda, copy_qdp_d2h, copy_qdp_h2d
+
+  ! mirror of tse_init_args (include/transport_se_hip.h)
+  type, bind(C) :: tse_init_args
+     integer(c_int) :: nelemd, qsize, device
+     real(c_double) :: nu_q
+     integer(c_int) :: limiter_option, rsplit
+     type(c_ptr)    :: Dvv, hyai, hybi
+     real(c_double) :: ps0
+     type(c_ptr)    :: Dinv;      integer(c_size_t) :: Dinv_stride
+     type(c_ptr)    :: metdet;    integer(c_size_t) :: metdet_stride
+     type(c_ptr)    :: rmetdet;   integer(c_size_t) :: rmetdet_stride
+     type(c_ptr)    :: spheremp;  integer(c_size_t) :: spheremp_stride
+     type(c_ptr)    :: rspheremp; integer(c_size_t) :: rspheremp_stride
+     type(c_ptr)    :: putmapP, getmapP, reverse
+     integer(c_int) :: nsend;  type(c_ptr) :: send_peer, send_ptrP, send_lengthP
+     integer(c_int) :: nrecv;  type(c_ptr) :: recv_peer, recv_ptrP, recv_lengthP
+     type(c_funptr) :: exchange; type(c_ptr) :: exchange_user
+  end type tse_init_args
+
+  interface
+     integer(c_int) function tse_init(ctx, args) bind(C, name='tse_init')
+       import; type(c_ptr), intent(out) :: ctx; type(tse_init_args), intent(in) :: args
+     end function
+     integer(c_int) function tse_copy_qdp_h2d(ctx, q, stride, qsize_d, nt) bind(C, name='tse_copy_qdp_h2d')
+       import; type(c_ptr), value :: ctx, q; integer(c_size_t), value :: stride; integer(c_int), value :: qsize_d, nt
+     end function
+     integer(c_int) function tse_copy_qdp_d2h(ctx, q, stride, qsize_d, nt) bind(C, name='tse_copy_qdp_d2h')
+       import; type(c_ptr), value :: ctx, q; integer(c_size_t), value :: stride; integer(c_int), value :: qsize_d, nt
+     end function
+     integer(c_int) function tse_set_derived(ctx, vn0, s0, dp, s1, eta, s2, omega, s3) bind(C, name='tse_set_derived')
+       import; type(c_ptr), value :: ctx, vn0, dp, eta, omega; integer(c_size_t), value :: s0, s1, s2, s3
+     end function
+     integer(c_int) function tse_set_divdp(ctx, divdp, s0, divdp_proj, s1) bind(C, name='tse_set_divdp')
+       import; type(c_ptr), value :: ctx, divdp, divdp_proj; integer(c_size_t), value :: s0, s1
+     end function
+     integer(c_int) function tse_get_derived(ctx, a, s1, b, s2, c, s3, d, s4, e, s5, f, s6) bind(C, name='tse_get_derived')
+       import; type(c_ptr), value :: ctx, a, b, c, d, e, f; integer(c_size_t), value :: s1, s2, s3, s4, s5, s6
+     end function
+     integer(c_int) function tse_euler_step(ctx, np1_qdp, n0_qdp, dt, DSSopt, rhs) bind(C, name='tse_euler_step')
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: np1_qdp, n0_qdp, DSSopt, rhs; real(c_double), value :: dt
+     end function
+     integer(c_int) function tse_qdp_time_avg(ctx, rkstage, n0_qdp, np1_qdp) bind(C, name='tse_qdp_time_avg')
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: rkstage, n0_qdp, np1_qdp
+     end function
+     integer(c_int) function tse_vertical_remap(ctx, dt, np1_qdp) bind(C, name='tse_vertical_remap')
+       import; type(c_ptr), value :: ctx; real(c_double), value :: dt; integer(c_int), value :: np1_qdp
+     end function
+     function tse_last_error() bind(C, name='tse_last_error') result(p)
+       import; type(c_ptr) :: p
+     end function
+  end interface
+
+  type(c_ptr), save :: ctx = c_null_ptr
+  integer(c_int), allocatable, target, save :: putm(:,:), getm(:,:), revm(:,:)
+  integer(c_int), allocatable, target, save :: speer(:), sptr(:), slen(:), rpeer(:), rptr(:), rlen(:)
+  real(c_double), allocatable, target, save :: dvv_c(:,:), hyai_c(:), hybi_c(:)
+
+contains
+
+  subroutine check(rc, where)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    character(len=400) :: text
+    integer :: i
+    if (rc == 0) return
+    call c_f_pointer(tse_last_error(), msg, [400])
+    text = ' '
+    do i = 1, 400
+       if (msg(i) == c_null_char) exit
+       text(i:i) = msg(i)
+    enddo
+    call abortmp(where//': '//trim(text))
+  end subroutine check
+
+  integer(c_size_t) function stride_of(a, b)
+    type(c_ptr), intent(in) :: a, b
+    stride_of = transfer(b, 0_c_size_t) - transfer(a, 0_c_size_t)
+  end function stride_of
+
+  ! cuda_mod_init(elem,hybrid,deriv,hvcoord)   (called at the end of prim_init2, prim_driver_mod.F90:686-689)
+  subroutine cuda_mod_init(elem, hybrid, deriv, hvcoord)
+    type(element_t),    intent(in), target :: elem(:)
+    type(hybrid_t),     intent(in) :: hybrid
+    type(derivative_t), intent(in) :: deriv
+    type(hvcoord_t),    intent(in) :: hvcoord
+    type(tse_init_args) :: a
+    integer :: ie, j, ns, nr, e2
+    if (hybrid%par%nprocs > 1) call abortmp('cuda_mod(hip): multi-rank halo callback not wired in this Fortran seam yet')
+    allocate(putm(8,nelemd), getm(8,nelemd), revm(8,nelemd))
+    do ie = 1, nelemd
+       putm(:,ie) = elem(ie)%desc%putmapP(1:8)
+       getm(:,ie) = elem(ie)%desc%getmapP(1:8)
+       do j = 1, 8
+          revm(j,ie) = merge(1, 0, elem(ie)%desc%reverse(j))
+       enddo
+    enddo
+    allocate(dvv_c(np,np), hyai_c(nlevp), hybi_c(nlevp))
+    dvv_c = deriv%Dvv; hyai_c = hvcoord%hyai; hybi_c = hvcoord%hybi
+    ns = 0; nr = 0
+    allocate(speer(1), sptr(1), slen(1), rpeer(1), rptr(1), rlen(1))
+    e2 = min(2, nelemd)
+    a%nelemd = nelemd; a%qsize = qsize; a%device = -1; a%nu_q = nu_q
+    a%limiter_option = limiter_option; a%rsplit = rsplit
+    a%Dvv = c_loc(dvv_c); a%hyai = c_loc(hyai_c); a%hybi = c_loc(hybi_c); a%ps0 = hvcoord%ps0
+    a%Dinv = c_loc(elem(1)%Dinv);           a%Dinv_stride = stride_of(c_loc(elem(1)%Dinv), c_loc(elem(e2)%Dinv))
+    a%metdet = c_loc(elem(1)%metdet);       a%metdet_stride = stride_of(c_loc(elem(1)%metdet), c_loc(elem(e2)%metdet))
+    a%rmetdet = c_loc(elem(1)%rmetdet);     a%rmetdet_stride = stride_of(c_loc(elem(1)%rmetdet), c_loc(elem(e2)%rmetdet))
+    a%spheremp = c_loc(elem(1)%spheremp);   a%spheremp_stride = stride_of(c_loc(elem(1)%spheremp), c_loc(elem(e2)%spheremp))
+    a%rspheremp = c_loc(elem(1)%rspheremp); a%rspheremp_stride = stride_of(c_loc(elem(1)%rspheremp), c_loc(elem(e2)%rspheremp))
+    a%putmapP = c_loc(putm); a%getmapP = c_loc(getm); a%reverse = c_loc(revm)
+    a%nsend = ns; a%send_peer = c_loc(speer); a%send_ptrP = c_loc(sptr); a%send_lengthP = c_loc(slen)
+    a%nrecv = nr; a%recv_peer = c_loc(rpeer); a%recv_ptrP = c_loc(rptr); a%recv_lengthP = c_loc(rlen)
+    a%exchange = c_null_funptr; a%exchange_user = c_null_ptr
+    call check(tse_init(ctx, a), 'cuda_mod_init')
+  end subroutine cuda_mod_init
+
+  integer(c_size_t) function estride(elem)
+    type(element_t), intent(in), target :: elem(:)
+    estride = stride_of(c_loc(elem(1)%state%Qdp), c_loc(elem(min(2,size(elem)))%state%Qdp))
+  end function estride
+
+  subroutine copy_qdp_h2d(elem, nt)
+    type(element_t), intent(in), target :: elem(:)
+    integer, intent(in) :: nt
+    call check(tse_copy_qdp_h2d(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_h2d')
+  end subroutine copy_qdp_h2d
+
+  subroutine copy_qdp_d2h(elem, nt)
+    type(element_t), intent(in), target :: elem(:)
+    integer, intent(in) :: nt
+    call check(tse_copy_qdp_d2h(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_d2h')
+  end subroutine copy_qdp_d2h
+
+  subroutine euler_step_cuda(np1_qdp, n0_qdp, dt, elem, hvcoord, hybrid, deriv, nets, nete, DSSopt, rhs_multiplier)
+    integer,              intent(in)            :: np1_qdp, n0_qdp
+    real(kind=real_kind), intent(in)            :: dt
+    type(element_t),      intent(inout), target :: elem(:)
+    type(hvcoord_t),      intent(in)            :: hvcoord
+    type(hybrid_t),       intent(in)            :: hybrid
+    type(derivative_t),   intent(in)            :: deriv
+    integer,              intent(in)            :: nets, nete, DSSopt, rhs_multiplier
+    integer(c_size_t) :: s
+    if (nets /= 1 .or. nete /= nelemd) call abortmp('euler_step_cuda(hip): needs NThreads=1 (nets:nete = 1:nelemd)')
+    s = estride(elem)   ! every field lives in the same fixed-size element_t, so one stride serves all
+    ! what euler_step_cuda stages from elem%derived on every call (cuda_mod.F90:535-547, 564-586)
+    call check(tse_set_derived(ctx, c_loc(elem(1)%derived%vn0), s, c_loc(elem(1)%derived%dp), s, &
+                               c_loc(elem(1)%derived%eta_dot_dpdn), s, c_loc(elem(1)%derived%omega_p), s), 'tse_set_derived')
+    call check(tse_set_divdp(ctx, c_loc(elem(1)%derived%divdp), s, c_loc(elem(1)%derived%divdp_proj), s), 'tse_set_divdp')
+    call check(tse_euler_step(ctx, int(np1_qdp,c_int), int(n0_qdp,c_int), dt, int(DSSopt,c_int), int(rhs_multiplier,c_int)), &
+               'euler_step_cuda')
+    call check(tse_get_derived(ctx, c_loc(elem(1)%derived%divdp_proj), s, c_loc(elem(1)%derived%eta_dot_dpdn), s, &
+                               c_loc(elem(1)%derived%omega_p), s, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, &
+                               c_null_ptr, 0_c_size_t), 'tse_get_derived')
+  end subroutine euler_step_cuda
+
+  subroutine qdp_time_avg_cuda(elem, rkstage, n0_qdp, np1_qdp, limiter_option, nu_p, nets, nete)
+    type(element_t),      intent(inout) :: elem(:)
+    real(kind=real_kind), intent(in)    :: nu_p
+    integer,              intent(in)    :: rkstage, n0_qdp, np1_qdp, nets, nete, limiter_option
+    call check(tse_qdp_time_avg(ctx, int(rkstage,c_int), int(n0_qdp,c_int), int(np1_qdp,c_int)), 'qdp_time_avg_cuda')
+  end subroutine qdp_time_avg_cuda
+
+  ! call site: vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,nets,nete)   (prim_advection_mod.F90:1280)
+  subroutine vertical_remap_cuda(elem, hvcoord, dt, np1, np1_qdp, nets, nete)
+    type(element_t),      intent(inout), target :: elem(:)
+    type(hvcoord_t),      intent(in)    :: hvcoord
+    real(kind=real_kind), intent(in)    :: dt
+    integer,              intent(in)    :: np1, np1_qdp, nets, nete
+    integer(c_size_t) :: s
+    integer :: ie
+    real(kind=real_kind), allocatable, target :: dp3d(:,:,:,:), psv(:,:,:)
+    s = estride(elem)
+    call check(tse_set_derived(ctx, c_null_ptr, 0_c_size_t, c_loc(elem(1)%derived%dp), s, c_null_ptr, 0_c_size_t, &
+                               c_null_ptr, 0_c_size_t), 'tse_set_derived')
+    call check(tse_set_divdp(ctx, c_null_ptr, 0_c_size_t, c_loc(elem(1)%derived%divdp_proj), s), 'tse_set_divdp')
+    call check(tse_vertical_remap(ctx, dt, int(np1_qdp,c_int)), 'vertical_remap_cuda')
+    ! state%dp3d(:,:,:,np1) and state%ps_v(:,:,np1) are time-level slices: stage through dense arrays
+    allocate(dp3d(np,np,nlev,nelemd), psv(np,np,nelemd))
+    call check(tse_get_derived(ctx, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, c_null_ptr, &
+                               0_c_size_t, c_loc(dp3d), int(np*np*nlev*8,c_size_t), c_loc(psv), int(np*np*8,c_size_t)), &
+               'tse_get_derived')
+    do ie = 1, nelemd
+       elem(ie)%state%dp3d(:,:,:,np1) = dp3d(:,:,:,ie)
+       elem(ie)%state%ps_v(:,:,np1)   = psv(:,:,ie)
+    enddo
+  end subroutine vertical_remap_cuda
+
+end module cuda_mod
