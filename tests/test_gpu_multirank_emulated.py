@@ -1,0 +1,93 @@
+"""-m gpu: the library's multi-rank code path (k_pack/k_pack_minmax, remote columns in k_dss/k_nbr_minmax, the six
+exchanges per tracer step) on ONE GPU: the sphere is cut into 2 and 3 "ranks", each a separate tse_ctx driven from its
+own thread; the exchange callback swaps the packed slots between the contexts with hipMemcpy.  The result must equal the
+single-context run BIT FOR BIT (north_star: BFB across GPU counts)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from transport_se_amd import cube_mesh as cm
+from transport_se_amd.driver import partition
+from transport_se_amd.hip_mod import HipMod
+from transport_se_amd.hybvcoord import HvCoord
+
+pytestmark = pytest.mark.gpu
+NE, QSIZE, NU_Q, DT = 4, 3, 5e17, 900.0
+
+
+def _run(world):
+    hv = HvCoord()
+    topo = cm.topology(NE); geo = cm.geometry(NE, topo)
+    nelem = 6 * NE * NE
+    owner = partition(nelem, world)
+    descs = [cm.edge_descriptors(topo, owner, r) for r in range(world)]
+    hip = C.CDLL("libamdhip64.so")
+    barrier = threading.Barrier(world)
+    bufs = [None] * world            # (sendbuf ptr, nlyr) published by each rank inside the callback
+    ctxs = [None] * world
+    result = [None] * world
+    errors = []
+
+    def make_exchange(r):
+        d = descs[r]
+        offs = np.concatenate([[0], np.cumsum([s[2] for s in d["send"]])]).astype(int)
+
+        def exchange(sbuf, rbuf, nlyr):
+            bufs[r] = (sbuf, nlyr)
+            barrier.wait()
+            for i, (peer, _, ln) in enumerate(d["recv"]):
+                pd = descs[peer]
+                poffs = np.concatenate([[0], np.cumsum([s[2] for s in pd["send"]])]).astype(int)
+                j = [k for k, s in enumerate(pd["send"]) if s[0] == r][0]
+                assert pd["send"][j][2] == ln and bufs[peer][1] == nlyr
+                src = bufs[peer][0] + int(poffs[j]) * nlyr * 8
+                dst = rbuf + int(offs[i]) * nlyr * 8
+                rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(ln * nlyr * 8), C.c_int(3))
+                assert rc == 0
+            barrier.wait()
+            return 0
+        return exchange
+
+    def worker(r):
+        try:
+            d = descs[r]; mine = d["elems"]
+            elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine],
+                        spheremp=geo["spheremp"][mine], rspheremp=geo["rspheremp"][mine],
+                        putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
+            h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), QSIZE, NU_Q, device=0,
+                       schedule=dict(send=d["send"], recv=d["recv"]), exchange=make_exchange(r) if world > 1 else None)
+            ctxs[r] = h
+            h.dcmip_init(1, geo["lat"][mine], geo["lon"][mine], hv.hyam, hv.hybm)
+            h.dcmip_set_initial()
+            assert h.prim_run_subcycle(DT, 2, 0) == 6
+            result[r] = (mine, h.fetch("qdp", (2, mine.size, QSIZE, 72, 4, 4))[0].copy(),
+                         h.fetch("divdp_proj", (mine.size, 72, 4, 4)).copy())
+            h.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append(ex)
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=240)
+    assert not errors, errors
+    q = np.empty((nelem, QSIZE, 72, 4, 4)); dv = np.empty((nelem, 72, 4, 4))
+    for mine, qq, dd in result:
+        q[mine] = qq; dv[mine] = dd
+    return q, dv
+
+
+def test_bfb_across_rank_counts():
+    q1, d1 = _run(1)
+    assert np.isfinite(q1).all() and q1.max() > 0
+    for world in (2, 3):
+        qn, dn = _run(world)
+        assert np.array_equal(qn, q1), "Qdp differs between 1 and %d ranks" % world
+        assert np.array_equal(dn, d1)

@@ -28,11 +28,16 @@ class HaloExchange:
     neighbour rank, message = nlyr * lengthP doubles, slot s at column offset sum(lengthP[:s])."""
 
     def __init__(self, sched, device, dist_mod, torch_mod):
+        """device: "cuda:N" (buffers are HIP device pointers) or "cpu" (host pointers; gloo tests)"""
         self.sched, self.dist, self.torch, self.device = sched, dist_mod, torch_mod, device
         self.off_s = np.concatenate([[0], np.cumsum([s[2] for s in sched["send"]])]).astype(int)
         self.off_r = np.concatenate([[0], np.cumsum([s[2] for s in sched["recv"]])]).astype(int)
 
     def _wrap(self, ptr, count):
+        if str(self.device) == "cpu":
+            import ctypes
+            arr = np.ctypeslib.as_array(ctypes.cast(int(ptr), ctypes.POINTER(ctypes.c_double)), shape=(int(count),))
+            return self.torch.from_numpy(arr)
         iface = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
         holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
         return self.torch.as_tensor(holder, device=self.device)
@@ -48,7 +53,8 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.isend, st[self.off_s[i] * nlyr:(self.off_s[i] + ln) * nlyr], int(peer)))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        torch.cuda.current_stream(self.device).synchronize()
+        if str(self.device) != "cpu":
+            torch.cuda.current_stream(self.device).synchronize()
         return 0
 
 
