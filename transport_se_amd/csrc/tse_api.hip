@@ -19,6 +19,8 @@
 
 using namespace tse;
 
+static const int DSS_QB = 5;  // tracers per k_dss_t block
+
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
@@ -379,25 +381,26 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
   if (c->ncol_send) {
     size_t tot = (size_t)c->ncol_send * nq;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, src,
-                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0);
+                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, 1);
     LAUNCH_CHECK();
     if (var) {
       size_t tv = (size_t)c->ncol_send * NLEV;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var_src,
-                         c->spheremp, c->sendbuf, nq + NLEV, nq);
+                         c->spheremp, c->sendbuf, nq + NLEV, nq, 0);
       LAUNCH_CHECK();
     }
   }
   if (halo_exchange(c, nq + NLEV)) return 1;
   {
     Scope s(c, "dss");
-    const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
+    const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
+    const dim3 grid(8 * ((c->nelemd + 7) / 8) * nqc);
     if (Qn0_avg)
-      hipLaunchKernelGGL(k_dss<1>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
+      hipLaunchKernelGGL(k_dss_t<1>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                         Qn0_avg, c->recvbuf, nq + NLEV);
     else
-      hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, 0, (const double*)nullptr);
+      hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                         (const double*)nullptr, c->recvbuf, nq + NLEV);
     LAUNCH_CHECK();
   }
   if (var) {
@@ -452,15 +455,15 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       // Laplacian and the bounds as two exchanges of the sizes the halo buffer is dimensioned for
       size_t tot = (size_t)c->ncol_send * nq;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->B,
-                         (const double*)nullptr, c->sendbuf, nq, 0);
+                         (const double*)nullptr, c->sendbuf, nq, 0, 1);
       LAUNCH_CHECK();
     }
     if (halo_exchange(c, nq)) return 1;
     {
       Scope s(c, "dss");
-      const int nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
-      hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, nq, nchunk, c->dss_tab, c->rspheremp, c->B, c->T,
-                         (const double*)nullptr, c->recvbuf, nq, 0, (const double*)nullptr);
+      const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
+      hipLaunchKernelGGL(k_dss_t<0>, dim3(8 * ((c->nelemd + 7) / 8) * nqc), dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
+                         c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq);
       LAUNCH_CHECK();
     }
     if (neighbor_minmax(c)) return 1;
@@ -592,3 +595,12 @@ int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {
   if (ms) *ms = it->second.ms; if (launches) *launches = it->second.n;
   return 0;
 }
+
+#ifdef TSE_LIMITER_STATS
+extern "C" int tse_debug_limiter_hist(unsigned long long* out, int reset) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(tse::g_lim_hist), sizeof(unsigned long long) * 20));
+  if (reset) { unsigned long long z[20] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(tse::g_lim_hist), z, sizeof z)); }
+  return 0;
+}
+#endif

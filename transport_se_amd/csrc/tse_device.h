@@ -144,8 +144,14 @@ __device__ __forceinline__ void laplace_sphere_wk_row(const Dvv_t& D, const RowG
 // x[i] = ptens/dpmass at the lane's 4 points, c[i] = sphweights*dpmass, sumc = sum(c) over the slab.
 // minp/maxp are relaxed in place (intent(inout) in the reference).  The 16-point sums are tree sums
 // (4 in-lane + quad butterfly) instead of the reference's serial k1 loop.
+#ifdef TSE_LIMITER_STATS
+__device__ unsigned long long g_lim_hist[20];  // [it] slabs converged at iteration it (16 = never), [17] wave-iterations, [18] waves
+#endif
 __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], double sumc, double& minp, double& maxp) {
   const double tol_limiter = (double)5e-14f;
+#ifdef TSE_LIMITER_STATS
+  int my_it = 16, wave_it = 0;
+#endif
   if (!(sumc > 0.0)) return;  // whole quad takes the same branch
   double mass = quad_sum(((c[0] * x[0] + c[1] * x[1]) + c[2] * x[2]) + c[3] * x[3]);
   if (mass < minp * sumc) minp = mass / sumc;
@@ -159,6 +165,10 @@ __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], do
     }
     addmass = quad_sum(addmass);
     bool done = fabs(addmass) <= tol_limiter * fabs(mass);
+#ifdef TSE_LIMITER_STATS
+    wave_it = iter;
+    if (done && my_it == 16) my_it = iter;
+#endif
     if (__all(done)) break;  // wave-uniform exit; slabs already converged are left untouched below
     double w = 0.0;
     if (addmass > 0.0) {
@@ -180,6 +190,10 @@ __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], do
       }
     }
   }
+#ifdef TSE_LIMITER_STATS
+  if ((threadIdx.x & 3) == 0) atomicAdd(&g_lim_hist[my_it], 1ull);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&g_lim_hist[17], (unsigned long long)wave_it); atomicAdd(&g_lim_hist[18], 1ull); }
+#endif
 }
 
 }  // namespace tse

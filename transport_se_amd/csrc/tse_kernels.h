@@ -75,16 +75,17 @@ __global__ void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
   const int e = (int)(t / m);
   const size_t l = t % m;
   double mn = in_min[t], mx = in_max[t];
+  // all 8 neighbour loads in flight together (a missing neighbour re-reads the element itself)
+  double nmn[8], nmx[8];
 #pragma unroll
   for (int d = 0; d < 8; d++) {
-    int n = nbr[e * 8 + d];
-    if (n >= 0) { mn = fmin(mn, in_min[(size_t)n * m + l]); mx = fmax(mx, in_max[(size_t)n * m + l]); }
-    else if (n <= -2) {
-      size_t col = (size_t)(-(n + 2));
-      mn = fmin(mn, recvbuf[col * nlyr_halo + l]);
-      mx = fmax(mx, recvbuf[col * nlyr_halo + m + l]);
-    }
+    const int n = nbr[e * 8 + d];
+    const double* pmn = n >= 0 ? in_min + (size_t)n * m + l : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + l : in_min + t);
+    const double* pmx = n >= 0 ? in_max + (size_t)n * m + l : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m + l : in_max + t);
+    nmn[d] = *pmn; nmx[d] = *pmx;
   }
+#pragma unroll
+  for (int d = 0; d < 8; d++) { mn = fmin(mn, nmn[d]); mx = fmax(mx, nmx[d]); }
   out_min[t] = mn; out_max[t] = mx;
 }
 
@@ -191,7 +192,11 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
     if (k < NLEV) {
-      store4(Tout + so, x);
+      // pre-DSS output in the gather-friendly layout T[e][q][p][k] (level fastest): the neighbours' edge points that
+      // k_dss_t adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
+      double* tp = Tout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;
+#pragma unroll
+      for (int i = 0; i < 4; i++) tp[(size_t)i * NLEV] = x[i];
       if (j == 0) { qmin[mi] = minp; qmax[mi] = maxp; }
     }
 #pragma unroll
@@ -226,7 +231,9 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_lap1(Dvv_t D, GeoPtrs G, int q
     double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     laplace_sphere_wk_row(D, g, x, l1);
     if (k < NLEV) {
-      store4(Bout + so, l1);
+      double* bp = Bout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;   // B[e][q][p][k], as T
+#pragma unroll
+      for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
       if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
     }
   }
@@ -297,15 +304,84 @@ __global__ __launch_bounds__(DSS_THREADS) void k_dss(int nelemd, int nlyr, int n
   if (active) store4(dst + off, v);
 }
 
+// Tracer-field DSS: source in the level-fastest layout src[e][q][p][k] written by k_advance/k_lap1, destination in the
+// standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
+// k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
+// Work items are ordered tracer-chunk-major and the 8 XCDs each walk a contiguous range of elements (see k_dss).
+template <int MODE>
+__global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
+                                                        const double* __restrict__ rspheremp, const double* __restrict__ src,
+                                                        double* __restrict__ dst, const double* __restrict__ Qn0,
+                                                        const double* __restrict__ recvbuf, int nlyr_halo) {
+  const int S8 = (nelemd + 7) >> 3;
+  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
+  const int e = xcd * S8 + it % S8, qc = it / S8;
+  if (e >= nelemd) return;
+  const int tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  // Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take up to 3 contributions
+  // (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot re-reads the
+  // lane's own value and is weighted 0) so that the 8 loads are in flight together -- a load inside a divergent
+  // branch is waited for on the spot, which serialises 8 memory latencies per tracer.
+  constexpr int NS = 8;
+  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
+  const double* gp[NS];   // address of the contribution for tracer q0, level kc
+  int gstride[NS];        // stride (doubles) from one tracer to the next
+  double gw[NS];          // 1 = take it, 0 = empty slot
+  const int q0 = qc * qb;
+  const double* own0 = src + (((size_t)e * qsize + q0) * 16 + j * 4) * NLEV + kc;
+  int2 tt[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];   // 8 loads in flight together
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int2 t = tt[s];
+    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + kc; gstride[s] = 16 * NLEV; gw[s] = 1.0; }
+    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + kc; gstride[s] = NLEV; gw[s] = 1.0; }
+    else { gp[s] = own0; gstride[s] = 16 * NLEV; gw[s] = 0.0; }
+  }
+  double rs[4];
+  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  const int q1 = min(qsize, (qc + 1) * qb);
+  for (int q = q0; q < q1; q++) {
+    const size_t dq = (size_t)(q - q0);
+    double v[4], a[NS];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = own0[dq * 16 * NLEV + (size_t)i * NLEV];
+#pragma unroll
+    for (int s = 0; s < NS; s++) a[s] = 0.0;
+    // loads only (predicated per lane); every use comes after the last load so that no wait lands between them
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+      if (gw[s] != 0.0) a[s] = gp[s][dq * gstride[s]];
+    // the reference's order: edge contributions (S, E, N, W) first, then the corner
+    v[0] = v[0] + gw[0] * a[0]; v[0] = v[0] + gw[1] * a[1]; v[0] = v[0] + gw[2] * a[2];
+    v[1] = v[1] + gw[3] * a[3];
+    v[2] = v[2] + gw[4] * a[4];
+    v[3] = v[3] + gw[5] * a[5]; v[3] = v[3] + gw[6] * a[6]; v[3] = v[3] + gw[7] * a[7];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
+    const size_t off = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
+    if (MODE == 1) {
+      double q0v[4];
+      load4(Qn0 + off, q0v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = (q0v[i] + 2 * v[i]) / 3;  // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
+    }
+    if (k < NLEV) store4(dst + off, v);
+  }
+}
+
 // pack the rank-boundary columns of a [e][nlyr][16] field into sendbuf[col][nlyr_halo] (layer fastest, the
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
-                       const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0) {
+                       const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
+                       int transposed /* src[e][q][p][k] instead of [e][lyr][p] */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nlyr) return;
   int col = (int)(t / nlyr), l = (int)(t % nlyr);
   int2 s = send_src[col];
-  double a = src[((size_t)s.x * nlyr + l) * 16 + s.y];
+  double a = transposed ? src[(((size_t)s.x * (nlyr / NLEV) + l / NLEV) * 16 + s.y) * NLEV + l % NLEV]
+                        : src[((size_t)s.x * nlyr + l) * 16 + s.y];
   if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
   sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
 }
