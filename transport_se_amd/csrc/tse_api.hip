@@ -20,6 +20,9 @@
 using namespace tse;
 
 static const int DSS_QB = 5;  // tracers per k_dss_t block
+// TSE_FUSE_STAGE3=1 selects the variant that folds the first Laplacian into the stage-2 DSS and the second Laplacian
+// into the Laplacian's DSS (two field passes fewer, but 170-190 VGPRs -> 5 waves/CU: slower at present)
+static bool fuse_stage3() { static int v = -1; if (v < 0) { const char* e = getenv("TSE_FUSE_STAGE3"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
 
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -371,7 +374,7 @@ static int neighbor_minmax(tse_ctx* c) {
 // DSS (+ inverse mass matrix) of a tracer-sized field src -> dst, together with the extra level variable
 // (spheremp*var packed behind the tracers: nlyr = qsize*nlev + nlev as edgeAdv_p1, prim_advection_mod.F90:497,911-919)
 static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double* var /* [e][NLEV or NLEVP][16] */, int var_levels,
-                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */) {
+                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0) {
   const int nq = c->qsize * NLEV;
   const double* var_src = var;
   if (var && var_levels != NLEV) {  // eta_dot_dpdn carries nlev+1 levels per element; DSS levels 1:nlev (:835-837)
@@ -397,10 +400,15 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     const dim3 grid(8 * ((c->nelemd + 7) / 8) * nqc);
     if (Qn0_avg)
       hipLaunchKernelGGL(k_dss_t<1>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV);
-    else
+                         Qn0_avg, c->recvbuf, nq + NLEV, DssExtra{});
+    else if (mode3) {
+      DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = rdt; X.dp = c->dp; X.divdp_proj = c->divdp_proj; X.qmin = c->qmin; X.qmax = c->qmax;
+      X.lapout = c->B;
+      hipLaunchKernelGGL(k_dss_t<3>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, X);
+    } else
       hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV);
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, DssExtra{});
     LAUNCH_CHECK();
   }
   if (var) {
@@ -418,7 +426,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
 }
 
 // one RK stage; fuse_avg: apply qdp_time_avg in the final DSS (whole-step path only)
-static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0) {
+static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false) {
   if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
@@ -443,7 +451,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
                        c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
     LAUNCH_CHECK();
   } else {
-    {
+    if (!fused) {   // in the fused whole-step path the stage-2 DSS (k_dss_t<3>) has already produced B, qmin, qmax
       Scope s(c, "lap");
       hipLaunchKernelGGL(k_lap1, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
@@ -462,19 +470,31 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     {
       Scope s(c, "dss");
       const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-      hipLaunchKernelGGL(k_dss_t<0>, dim3(8 * ((c->nelemd + 7) / 8) * nqc), dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
-                         c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq);
+      const dim3 g2(8 * ((c->nelemd + 7) / 8) * nqc);
+      if (fused) {  // DSS + inverse mass + second Laplacian + biharmonic scaling in one pass: T = biharmonic term
+        DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = dt; X.nu_q = c->nu_q; X.dp0 = c->dp0;
+        hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
+                           (const double*)nullptr, c->recvbuf, nq, X);
+      } else {
+        hipLaunchKernelGGL(k_dss_t<0>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
+                           (const double*)nullptr, c->recvbuf, nq, DssExtra{});
+      }
       LAUNCH_CHECK();
     }
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
-    hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                       c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    if (fused)
+      hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    else
+      hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0);
     LAUNCH_CHECK();
   }
   const double* pre = rhs == 2 ? c->B : c->T;
   const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
-  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg);
+  // fused path: the stage-2 DSS also forms Q = Qdp/dp for stage 3 (dp uses rhs_multiplier 2 and the stage dt)
+  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg, fused && rhs == 1, 2 * dt);
 }
 
 int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
@@ -493,9 +513,10 @@ int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
 int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) {
   if (n0_qdp == np1_qdp) return fail("advec_tracers_remap_rk2: n0_qdp == np1_qdp");
   if (tse_compute_divdp(c)) return 1;
-  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp)) return 1;
+  const bool f = fuse_stage3();
+  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, f)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, f)) return 1;
   return 0;
 }
 

@@ -140,6 +140,43 @@ __device__ __forceinline__ void laplace_sphere_wk_row(const Dvv_t& D, const RowG
   }
 }
 
+// Register-lean form of laplace_sphere_wk for the fused kernels: with v = rrearth*(ds/dx, ds/dy),
+//   vtemp = Dinv * (Dinv^T v)  =  [A B; B C] v,  A = Di11^2+Di12^2, B = Di11*Di21+Di12*Di22, C = Di21^2+Di22^2
+// so only the 3 entries of the symmetric tensor spheremp*rrearth^2*[A B; B C] are kept per point (12 doubles per
+// lane instead of 20); same operator as derivative_mod.F90:2418-2460, products re-associated.
+struct LapGeo { double A[4], B[4], C[4], dcol[4], drow[4]; };
+__device__ __forceinline__ void make_lap_geo(LapGeo& L, const RowGeo& g) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double s = g.spheremp[i] * (RREARTH * RREARTH);
+    L.A[i] = s * (g.Di11[i] * g.Di11[i] + g.Di12[i] * g.Di12[i]);
+    L.B[i] = s * (g.Di11[i] * g.Di21[i] + g.Di12[i] * g.Di22[i]);
+    L.C[i] = s * (g.Di21[i] * g.Di21[i] + g.Di22[i] * g.Di22[i]);
+    L.dcol[i] = g.dcol[i]; L.drow[i] = g.drow[i];
+  }
+}
+__device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L, const double s[4], double lap[4]) {
+  // written point-by-point so that only one set of 4 quad broadcasts is live at a time (register pressure)
+  double w1[4], w2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const double dx = ((D.d[i * 4] * s[0] + D.d[i * 4 + 1] * s[1]) + D.d[i * 4 + 2] * s[2]) + D.d[i * 4 + 3] * s[3];
+    const double dy = ((L.dcol[0] * quad_bcast<0>(s[i]) + L.dcol[1] * quad_bcast<1>(s[i])) + L.dcol[2] * quad_bcast<2>(s[i])) +
+                      L.dcol[3] * quad_bcast<3>(s[i]);
+    w1[i] = L.A[i] * dx + L.B[i] * dy;
+    w2[i] = L.B[i] * dx + L.C[i] * dy;
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) {
+    double d = 0.0;
+    d = d - (w1[0] * D.d[0 * 4 + m] + quad_bcast<0>(w2[m]) * L.drow[0]);
+    d = d - (w1[1] * D.d[1 * 4 + m] + quad_bcast<1>(w2[m]) * L.drow[1]);
+    d = d - (w1[2] * D.d[2 * 4 + m] + quad_bcast<2>(w2[m]) * L.drow[2]);
+    d = d - (w1[3] * D.d[3 * 4 + m] + quad_bcast<3>(w2[m]) * L.drow[3]);
+    lap[m] = d;
+  }
+}
+
 // limiter_optim_iter_full (prim_advection_mod.F90:976-1094) on one slab spread over a quad.
 // x[i] = ptens/dpmass at the lane's 4 points, c[i] = sphweights*dpmass, sumc = sum(c) over the slab.
 // minp/maxp are relaxed in place (intent(inout) in the reference).  The 16-point sums are tree sums

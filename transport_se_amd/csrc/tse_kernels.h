@@ -107,8 +107,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
   //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
   double a1[4], a2[4], rm[4], dps[4], rdps[4], c[4], spm[4], rdpk[4], dcol[4];
-  RowGeo* gl = nullptr;  // the full metric row is only needed for the Laplacian of stage 3
-  RowGeo gfull;
+  LapGeo L;  // only used by the Laplacian of stage 3 (RHS == 2)
   {
     RowGeo g;
     load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      dpk[i] = dpk[i] - RHS * dt * t0[i];
+      dpk[i] = dpk[i] - (RHS == 3 ? 2 : RHS) * dt * t0[i];
       dps[i] = dpk[i] - dt * t1[i];
       rdps[i] = 1.0 / dps[i];
       rdpk[i] = 1.0 / dpk[i];
@@ -131,8 +130,9 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
       c[i] = spm[i] * dps[i];
       dcol[i] = g.dcol[i];
     }
-    if (RHS == 2) { gfull = g; gl = &gfull; }
+    if (RHS == 2) make_lap_geo(L, g);
   }
+  // RHS == 3: stage 3 (rhs_multiplier 2) with the biharmonic term already formed by k_dss_t<2> in `lap`
   const double sumc = quad_sum(((c[0] + c[1]) + c[2]) + c[3]);
   double visc[4];
 #pragma unroll
@@ -143,14 +143,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
   size_t mi = (size_t)e * qsize * NLEV + kc;
   double qn[4], ls[4], minp, maxp;
   load4(Qn0 + so, qn);
-  if (RHS == 2) load4(lap + so, ls);
+  if (RHS >= 2) load4(lap + so, ls);
   minp = qmin[mi]; maxp = qmax[mi];
   for (int q = 0; q < qsize; q++) {
     // software prefetch of the next tracer's slab row + bounds (vmcnt is in-order: issue everything for q+1 first)
     double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0, maxx = 0;
     if (q + 1 < qsize) {
       load4(Qn0 + so + qstride, qnx);
-      if (RHS == 2) load4(lap + so + qstride, lsx);
+      if (RHS >= 2) load4(lap + so + qstride, lsx);
       minx = qmin[mi + NLEV]; maxx = qmax[mi + NLEV];
     }
     double gv1[4], gv2[4], x[4], dx[4], dy[4];
@@ -182,9 +182,13 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
     }
     if (RHS == 2) {
       double l2[4];
-      laplace_sphere_wk_row(D, *gl, ls, l2);
+      laplace_lean_row(D, L, ls, l2);
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = x[i] + visc[i] * l2[i];
+    }
+    if (RHS == 3) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = x[i] + ls[i];
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
@@ -214,22 +218,26 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_lap1(Dvv_t D, GeoPtrs G, int q
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax) {
   const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
-  RowGeo g;
-  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  LapGeo L;
+  {
+    RowGeo g;
+    load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+    make_lap_geo(L, g);
+  }
   const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
   double dpk[4], dv[4];
   load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
 #pragma unroll
-  for (int i = 0; i < 4; i++) dpk[i] = dpk[i] - rdt * dv[i];
+  for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   for (int q = 0; q < qsize; q++) {
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
     double x[4], l1[4];
     load4(Qn0 + so, x);
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = x[i] / dpk[i];
+    for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
     double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
-    laplace_sphere_wk_row(D, g, x, l1);
+    laplace_lean_row(D, L, x, l1);
     if (k < NLEV) {
       double* bp = Bout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;   // B[e][q][p][k], as T
 #pragma unroll
@@ -308,11 +316,24 @@ __global__ __launch_bounds__(DSS_THREADS) void k_dss(int nelemd, int nlyr, int n
 // standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
 // k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
 // Work items are ordered tracer-chunk-major and the 8 XCDs each walk a contiguous range of elements (see k_dss).
+// MODE 0: dst = rspheremp * DSS(src)                                   (prim_advection_mod.F90:929-960)
+// MODE 1: ... fused with qdp_time_avg: dst = (Qn0 + 2*that)/3         (:645-662)
+// MODE 2: src = first Laplacian: dst = -3 dt nu_q dp0(k) * laplace_sphere_wk(rspheremp*DSS(src)) / spheremp, the
+//         biharmonic term euler_step adds in stage 3 (viscosity_mod.F90:419-423, prim_advection_mod.F90:813-826)
+// MODE 3: stage-2 DSS that also starts stage 3: dst = Qdp(np1) as MODE 0, plus Q = Qdp/dp (dp = derived%dp -
+//         2 dt divdp_proj), element min/max -> qmin/qmax, first Laplacian -> lapout in the level-fastest layout
+//         (prim_advection_mod.F90:750-761,796-809, viscosity_mod.F90:378-389)
+struct DssExtra {
+  Dvv_t D; GeoPtrs G;
+  double dt, nu_q;                 // MODE 2: stage dt ; MODE 3: rdt = 2*dt in `dt`
+  const double* dp0;               // MODE 2
+  const double* dp; const double* divdp_proj; double* qmin; double* qmax; double* lapout;   // MODE 3
+};
 template <int MODE>
 __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
                                                         const double* __restrict__ rspheremp, const double* __restrict__ src,
                                                         double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                        const double* __restrict__ recvbuf, int nlyr_halo) {
+                                                        const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X) {
   const int S8 = (nelemd + 7) >> 3;
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
   const int e = xcd * S8 + it % S8, qc = it / S8;
@@ -325,8 +346,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
   constexpr int NS = 8;
   const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
   const double* gp[NS];   // address of the contribution for tracer q0, level kc
-  int gstride[NS];        // stride (doubles) from one tracer to the next
-  double gw[NS];          // 1 = take it, 0 = empty slot
+  unsigned gvalid = 0, gremote = 0;   // bit s: slot populated / comes from the halo buffer (tracer stride NLEV)
   const int q0 = qc * qb;
   const double* own0 = src + (((size_t)e * qsize + q0) * 16 + j * 4) * NLEV + kc;
   int2 tt[NS];
@@ -335,12 +355,29 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
 #pragma unroll
   for (int s = 0; s < NS; s++) {
     const int2 t = tt[s];
-    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + kc; gstride[s] = 16 * NLEV; gw[s] = 1.0; }
-    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + kc; gstride[s] = NLEV; gw[s] = 1.0; }
-    else { gp[s] = own0; gstride[s] = 16 * NLEV; gw[s] = 0.0; }
+    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + kc; gvalid |= 1u << s; }
+    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + kc; gvalid |= 1u << s; gremote |= 1u << s; }
+    else gp[s] = own0;
   }
   double rs[4];
   load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  LapGeo L;
+  double visc[4] = {0, 0, 0, 0}, rdpk[4] = {0, 0, 0, 0};
+  if (MODE == 2 || MODE == 3) {
+    RowGeo g;
+    load_row_geo(g, X.D, X.G.Dinv, X.G.metdet, X.G.rmetdet, X.G.spheremp, e, j);
+    make_lap_geo(L, g);
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) visc[i] = (-3.0 * X.dt * X.nu_q * X.dp0[kc]) / g.spheremp[i];
+    }
+  }
+  if (MODE == 3) {
+    double d0[4], d1[4];
+    load4(X.dp + ((size_t)e * NLEV + kc) * 16 + j * 4, d0); load4(X.divdp_proj + ((size_t)e * NLEV + kc) * 16 + j * 4, d1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) rdpk[i] = 1.0 / (d0[i] - X.dt * d1[i]);
+  }
   const int q1 = min(qsize, (qc + 1) * qb);
   for (int q = q0; q < q1; q++) {
     const size_t dq = (size_t)(q - q0);
@@ -352,12 +389,12 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
     // loads only (predicated per lane); every use comes after the last load so that no wait lands between them
 #pragma unroll
     for (int s = 0; s < NS; s++)
-      if (gw[s] != 0.0) a[s] = gp[s][dq * gstride[s]];
-    // the reference's order: edge contributions (S, E, N, W) first, then the corner
-    v[0] = v[0] + gw[0] * a[0]; v[0] = v[0] + gw[1] * a[1]; v[0] = v[0] + gw[2] * a[2];
-    v[1] = v[1] + gw[3] * a[3];
-    v[2] = v[2] + gw[4] * a[4];
-    v[3] = v[3] + gw[5] * a[5]; v[3] = v[3] + gw[6] * a[6]; v[3] = v[3] + gw[7] * a[7];
+      if (gvalid & (1u << s)) a[s] = gp[s][dq * ((gremote & (1u << s)) ? NLEV : 16 * NLEV)];
+    // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
+    v[0] = v[0] + a[0]; v[0] = v[0] + a[1]; v[0] = v[0] + a[2];
+    v[1] = v[1] + a[3];
+    v[2] = v[2] + a[4];
+    v[3] = v[3] + a[5]; v[3] = v[3] + a[6]; v[3] = v[3] + a[7];
 #pragma unroll
     for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
     const size_t off = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
@@ -367,7 +404,27 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
 #pragma unroll
       for (int i = 0; i < 4; i++) v[i] = (q0v[i] + 2 * v[i]) / 3;  // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
     }
+    if (MODE == 2) {
+      double l2[4];
+      laplace_lean_row(X.D, L, v, l2);
+#pragma unroll
+      for (int i = 0; i < 4; i++) v[i] = visc[i] * l2[i];
+    }
     if (k < NLEV) store4(dst + off, v);
+    if (MODE == 3) {
+      double x[4], l1[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) x[i] = v[i] * rdpk[i];
+      double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
+      double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+      laplace_lean_row(X.D, L, x, l1);
+      if (k < NLEV) {
+        double* bp = X.lapout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;
+#pragma unroll
+        for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
+        if (j == 0) { X.qmin[((size_t)e * qsize + q) * NLEV + k] = mn; X.qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
+      }
+    }
   }
 }
 
