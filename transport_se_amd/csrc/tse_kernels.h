@@ -470,9 +470,11 @@ __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0
 // 5-cell window of cell means in registers (kid(k) >= k-1 by construction of the search, :160-166, so the
 // in-place update never overtakes the reads).
 constexpr int REMAP_THREADS = 576;
+constexpr int REMAP_PF = 8;  // column loads kept in flight per thread
 struct RemapLds {
   double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
   double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
+  double rdpo[NLEV + 4][16];       // 1/dpo (the column loop multiplies instead of dividing)
   double z2[NLEV][16];
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
@@ -528,6 +530,7 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
   }
   __syncthreads();
   // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260), one (j,p) per work item
+  for (int w = tid; w < (NLEV + 4) * 16; w += REMAP_THREADS) S.rdpo[w >> 4][w & 15] = 1.0 / S.dpo[w >> 4][w & 15];
   for (int w = tid; w < (NLEV + 2) * 16; w += REMAP_THREADS) {
     const int jj = w >> 4, p = w & 15;  // jj = j, j = 0..NLEV+1
 #define DX(j) S.dpo[(j) + 1][p]
@@ -550,13 +553,21 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
   const int p = tid & 15;
   for (int q = tid >> 4; q < qsize; q += REMAP_THREADS / 16) {
     double* col = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
-    int R = 0;                                   // highest cell fetched so far (ghost cells continue past NLEV)
+    // Cells are consumed strictly in order 1,2,3,...; a register FIFO keeps REMAP_PF column loads in flight per thread
+    // (one thread streams one column: without it only a single 8-byte load per lane would be outstanding).
+    int R = 0;                                   // highest cell consumed so far (ghost cells continue past NLEV)
+    double pf[REMAP_PF];
+#pragma unroll
+    for (int t = 0; t < REMAP_PF; t++) pf[t] = col[(size_t)t * 16];
     double pm1 = 0, pa1 = 0, pm2 = 0, pa2 = 0;   // the last two real cells (mass, mean) for the bottom mirror
     auto read_next = [&](double& m, double& a) {
       R++;
       if (R <= NLEV) {
-        m = col[(size_t)(R - 1) * 16];
-        a = m / S.dpo[R + 1][p];
+        m = pf[0];
+#pragma unroll
+        for (int t = 0; t + 1 < REMAP_PF; t++) pf[t] = pf[t + 1];
+        if (R + REMAP_PF <= NLEV) pf[REMAP_PF - 1] = col[(size_t)(R + REMAP_PF - 1) * 16];
+        a = m * S.rdpo[R + 1][p];
         pm2 = pm1; pa2 = pa1; pm1 = m; pa1 = a;
       } else if (R == NLEV + 1) { m = pm1; a = pa1; }   // a(nlev+1) = a(nlev)
       else { m = pm2; a = pa2; }                         // a(nlev+2) = a(nlev-1)
@@ -582,8 +593,8 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
     auto make_coefs = [&]() {
       double al = ai_m1, ar = ai_0;
       if ((ar - a0) * (a0 - al) <= 0.) { al = a0; ar = a0; }
-      if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) / 6.) al = 3. * a0 - 2. * ar;
-      if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) / 6.) ar = 3. * a0 - 2. * al;
+      if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) * (1.0 / 6.0)) al = 3. * a0 - 2. * ar;
+      if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) * (1.0 / 6.0)) ar = 3. * a0 - 2. * al;
       c0 = 1.5 * a0 - (al + ar) / 4.;
       c1 = ar - al;
       c2 = -6. * a0 + 3. * (al + ar);
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
         make_coefs();
       }
       const double x1 = -0.5, x2 = S.z2[k - 1][p];
-      double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) / 0.2e1 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) / 0.3e1;
+      double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) * 0.5 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) * (1.0 / 3.0);
       double massn2 = masso_kk + integ * S.dpo[kk + 1][p];
       col[(size_t)(k - 1) * 16] = massn2 - massn1;
       massn1 = massn2;
