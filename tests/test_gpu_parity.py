@@ -164,3 +164,18 @@ def test_limiter_edge_cases_through_the_step(ctx5):
     hip.copy_qdp_d2h(elem, 2)
     for q in range(5):
         assert relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q]) < 20 * TOL_STEP, q
+
+
+def test_many_tracers_qsize_40():
+    """qsize > 36 exercises the tracer-chunk loops (k_remap walks tracers 36 at a time, k_dss_t 5 at a time);
+    BASELINE configs[4] stresses qsize=200."""
+    o = po.Oracle(2, 40, nu_q=1e19)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+    o.dcmip_init(1)
+    assert hip.prim_run_subcycle(1800.0, 1, 0) == 3
+    done, _ = o.prim_run(1, 1800.0, 1)
+    hip.copy_qdp_d2h(elem, 2)
+    assert relerr(elem["Qdp"][:, 1], o.qdp[1]) < 6 * TOL_STEP
+    hip.close(); o.close()
