@@ -363,10 +363,12 @@ static int neighbor_minmax(tse_ctx* c) {
     LAUNCH_CHECK();
   }
   if (halo_exchange(c, 2 * m)) return 1;
-  size_t tot = (size_t)c->nelemd * m;
-  hipLaunchKernelGGL(k_nbr_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,
-                     c->qmax, c->qmin2, c->qmax2, c->recvbuf, 2 * m);
-  LAUNCH_CHECK();
+  {
+    Scope s(c, "minmax");
+    hipLaunchKernelGGL(k_nbr_minmax, dim3(8 * ((c->nelemd + 7) / 8)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,
+                       c->qmax, c->qmin2, c->qmax2, c->recvbuf, 2 * m);
+    LAUNCH_CHECK();
+  }
   std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
   return 0;
 }

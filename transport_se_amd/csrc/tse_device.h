@@ -193,39 +193,39 @@ __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], do
   double mass = quad_sum(((c[0] * x[0] + c[1] * x[1]) + c[2] * x[2]) + c[3] * x[3]);
   if (mass < minp * sumc) minp = mass / sumc;
   if (mass > maxp * sumc) maxp = mass / sumc;
+  const double tol_mass = tol_limiter * fabs(mass);
   for (int iter = 1; iter <= NP * NP - 1; iter++) {
+    // clip to [minp,maxp]; the removed mass is sum (x - clipped)*c: (x-maxp)*c above, -(minp-x)*c below, +0 inside --
+    // the same terms in the same order as the reference's two branches (:1037-1046), with v_min/v_max instead of
+    // compare+select pairs
     double addmass = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (x[i] > maxp) { addmass = addmass + (x[i] - maxp) * c[i]; x[i] = maxp; }
-      if (x[i] < minp) { addmass = addmass - (minp - x[i]) * c[i]; x[i] = minp; }
+      const double xc = fmin(fmax(x[i], minp), maxp);
+      addmass = addmass + (x[i] - xc) * c[i];
+      x[i] = xc;
     }
     addmass = quad_sum(addmass);
-    bool done = fabs(addmass) <= tol_limiter * fabs(mass);
+    const bool done = fabs(addmass) <= tol_mass;
 #ifdef TSE_LIMITER_STATS
     wave_it = iter;
     if (done && my_it == 16) my_it = iter;
 #endif
     if (__all(done)) break;  // wave-uniform exit; slabs already converged are left untouched below
+    // redistribute over the points that are not pinned at the bound the mass moves towards (:1052-1078)
+    const bool up = addmass > 0.0;
+    const double bound = up ? maxp : minp;
     double w = 0.0;
-    if (addmass > 0.0) {
+    bool fr[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) if (x[i] < maxp) w = w + c[i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) if (x[i] > minp) w = w + c[i];
+    for (int i = 0; i < 4; i++) {
+      fr[i] = up ? (x[i] < bound) : (x[i] > bound);
+      w = w + (fr[i] ? c[i] : 0.0);
     }
     w = quad_sum(w);
-    if (!done) {
-      double inc = addmass / w;
-      if (addmass > 0.0) {
+    const double inc = done ? 0.0 : addmass / w;
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (x[i] < maxp) x[i] = x[i] + inc;
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; i++) if (x[i] > minp) x[i] = x[i] + inc;
-      }
-    }
+    for (int i = 0; i < 4; i++) x[i] = fr[i] ? x[i] + inc : x[i];
   }
 #ifdef TSE_LIMITER_STATS
   if ((threadIdx.x & 3) == 0) atomicAdd(&g_lim_hist[my_it], 1ull);

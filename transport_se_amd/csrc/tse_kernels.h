@@ -66,27 +66,32 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_qminmax(int qsize, double rdt 
 // neighbor_minmax / min-max half of biharmonic_wk_scalar_minmax (viscosity_mod.F90:748-816,389-432):
 // min/max over the element and its <= 8 neighbours.  nbr[e][8]: >= 0 local element, -1 none,
 // <= -2 remote: column -(v+2) of the received halo (layer index = (q*NLEV+k), min set then max set).
-__global__ void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr, const double* __restrict__ in_min,
-                             const double* __restrict__ in_max, double* __restrict__ out_min, double* __restrict__ out_max,
-                             const double* __restrict__ recvbuf, int nlyr_halo) {
-  const size_t m = (size_t)qsize * NLEV;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)nelemd * m) return;
-  const int e = (int)(t / m);
-  const size_t l = t % m;
-  double mn = in_min[t], mx = in_max[t];
-  // all 8 neighbour loads in flight together (a missing neighbour re-reads the element itself)
-  double nmn[8], nmx[8];
+__global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
+                                                    const double* __restrict__ in_min, const double* __restrict__ in_max,
+                                                    double* __restrict__ out_min, double* __restrict__ out_max,
+                                                    const double* __restrict__ recvbuf, int nlyr_halo) {
+  // block = element; the 8 XCDs each walk a contiguous range of elements so that an element's bounds are re-read by
+  // its neighbours out of the same L2 (every value is needed by up to 9 elements)
+  const int S8 = (nelemd + 7) >> 3;
+  const int e = (blockIdx.x & 7) * S8 + (blockIdx.x >> 3);
+  if (e >= nelemd) return;
+  const int m = qsize * NLEV;
+  const double *pmn[8], *pmx[8];
 #pragma unroll
   for (int d = 0; d < 8; d++) {
     const int n = nbr[e * 8 + d];
-    const double* pmn = n >= 0 ? in_min + (size_t)n * m + l : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + l : in_min + t);
-    const double* pmx = n >= 0 ? in_max + (size_t)n * m + l : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m + l : in_max + t);
-    nmn[d] = *pmn; nmx[d] = *pmx;
+    pmn[d] = n >= 0 ? in_min + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo : in_min + (size_t)e * m);
+    pmx[d] = n >= 0 ? in_max + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m : in_max + (size_t)e * m);
   }
+  for (int l = threadIdx.x; l < m; l += 256) {
+    double mn = in_min[(size_t)e * m + l], mx = in_max[(size_t)e * m + l];
+    double nmn[8], nmx[8];   // all 16 neighbour loads in flight together
 #pragma unroll
-  for (int d = 0; d < 8; d++) { mn = fmin(mn, nmn[d]); mx = fmax(mx, nmx[d]); }
-  out_min[t] = mn; out_max[t] = mx;
+    for (int d = 0; d < 8; d++) { nmn[d] = pmn[d][l]; nmx[d] = pmx[d][l]; }
+#pragma unroll
+    for (int d = 0; d < 8; d++) { mn = fmin(mn, nmn[d]); mx = fmax(mx, nmx[d]); }
+    out_min[(size_t)e * m + l] = mn; out_max[(size_t)e * m + l] = mx;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
