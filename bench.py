@@ -80,11 +80,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    backend = os.environ.get("TSE_DIST_BACKEND", "nccl")   # "gloo": rehearsal with host-staged slots (ranks may share a GPU)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from transport_se_amd.driver import PrimRun
-    run = PrimRun(a.ne, a.qsize, test_case=1, rank=rank, world=world, device=local, dist_mod=dist, torch_mod=torch)
+    run = PrimRun(a.ne, a.qsize, test_case=1, rank=rank, world=world, device=local, dist_mod=dist, torch_mod=torch,
+                  stage_through_host=(backend != "nccl"))
 
     def barrier():
         run.hip.synchronize(); torch.cuda.synchronize()
@@ -100,10 +106,16 @@ def main():
     run.run(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    np1_final = 2 if ((a.warmup + a.steps) % 2 == 1) else 1     # TimeLevel_Qdp: the last step wrote 3 - n0
+    checksum = run.state_checksum(np1_final, torch)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local)
+        dev = "cuda:%d" % local if backend == "nccl" else "cpu"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        cs = torch.tensor([checksum], dtype=torch.int64, device=dev)
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+        checksum = int(cs.item())
     ktimes = {k: run.hip.kernel_time(k) for k in ("advance", "dss", "lap", "minmax", "remap", "level", "dcmip", "avg")}
     run.hip.timing(False)
     if rank == 0:
@@ -127,6 +139,9 @@ def main():
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
                          "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (a.gpus * HBM_PEAK_GBS * 1e9)},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in ktimes.items()},
+            # wrap-around int64 sum of the bit patterns of the final Qdp over all ranks: equal for every --gpus N
+            # (same steps/warmup) iff the result is bit-for-bit independent of the partition
+            "state_checksum": checksum & 0xFFFFFFFFFFFFFFFF,
         }
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.qsize)

@@ -27,9 +27,12 @@ class HaloExchange:
     """bndry_exchangeV (bndry_mod.F90:74-124) on device-resident packed slots: one isend + one irecv per
     neighbour rank, message = nlyr * lengthP doubles, slot s at column offset sum(lengthP[:s])."""
 
-    def __init__(self, sched, device, dist_mod, torch_mod):
-        """device: "cuda:N" (buffers are HIP device pointers) or "cpu" (host pointers; gloo tests)"""
+    def __init__(self, sched, device, dist_mod, torch_mod, stage_through_host=False):
+        """device: "cuda:N" (buffers are HIP device pointers) or "cpu" (host pointers; gloo tests).
+        stage_through_host: copy the device slots to the host and exchange them with a CPU backend (gloo) -- lets
+        several ranks share one GPU for rehearsals; the production path sends the device buffers with RCCL."""
         self.sched, self.dist, self.torch, self.device = sched, dist_mod, torch_mod, device
+        self.stage = stage_through_host
         self.off_s = np.concatenate([[0], np.cumsum([s[2] for s in sched["send"]])]).astype(int)
         self.off_r = np.concatenate([[0], np.cumsum([s[2] for s in sched["recv"]])]).astype(int)
 
@@ -46,6 +49,10 @@ class HaloExchange:
         torch, dist = self.torch, self.dist
         ns, nr = int(self.off_s[-1]), int(self.off_r[-1])
         st = self._wrap(sbuf, ns * nlyr); rt = self._wrap(rbuf, nr * nlyr)
+        rt_dev = None
+        if self.stage and str(self.device) != "cpu":
+            rt_dev = rt
+            st = st.cpu(); rt = torch.empty(nr * nlyr, dtype=torch.float64)
         ops = []
         for i, (peer, _, ln) in enumerate(self.sched["recv"]):
             ops.append(dist.P2POp(dist.irecv, rt[self.off_r[i] * nlyr:(self.off_r[i] + ln) * nlyr], int(peer)))
@@ -53,6 +60,8 @@ class HaloExchange:
             ops.append(dist.P2POp(dist.isend, st[self.off_s[i] * nlyr:(self.off_s[i] + ln) * nlyr], int(peer)))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        if rt_dev is not None:
+            rt_dev.copy_(rt)
         if str(self.device) != "cpu":
             torch.cuda.current_stream(self.device).synchronize()
         return 0
@@ -60,7 +69,7 @@ class HaloExchange:
 
 class PrimRun:
     def __init__(self, ne, qsize, test_case=1, nu_q=None, tstep=None, rsplit=3, rank=0, world=1, device=0,
-                 dist_mod=None, torch_mod=None):
+                 dist_mod=None, torch_mod=None, stage_through_host=False):
         self.ne, self.qsize, self.rsplit, self.test_case = ne, qsize, rsplit, test_case
         self.nu_q = NU_Q.get(ne, 1e15 * (30.0 / ne) ** 3.2) if nu_q is None else nu_q
         self.tstep = TSTEP.get(ne, 300.0 * 30.0 / ne) if tstep is None else tstep
@@ -78,7 +87,9 @@ class PrimRun:
         self.lat, self.lon = geo["lat"][mine], geo["lon"][mine]
         exchange = None
         if world > 1:
-            exchange = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod)
+            exchange = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod, stage_through_host)
+        self._exchange = exchange
+        self.hip_device = device
         self.hip = HipMod(self.elem, cm.dvv(), (self.hv.hyai, self.hv.hybi, self.hv.ps0), qsize, self.nu_q,
                           rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=exchange)
         self.hip.dcmip_init(test_case, self.lat, self.lon, self.hv.hyam, self.hv.hybm)
@@ -101,6 +112,17 @@ class PrimRun:
         for _ in range(nsteps):
             np1 = self.step()
         return np1
+
+    def state_checksum(self, tl, torch_mod):
+        """order-independent checksum of Qdp(:,:,:,:,tl) on this rank: the wrap-around int64 sum of the bit patterns
+        (summing it over ranks gives a number that is identical for every partition iff the fields are bit-for-bit equal)"""
+        ptr, nbytes = self.hip.device_ptr("qdp")
+        n = self.mine.size * self.qsize * 72 * 16
+        self.hip.synchronize()
+        iface = {"shape": (n,), "typestr": "<i8", "data": (int(ptr) + (tl - 1) * n * 8, False), "version": 2}
+        holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
+        t = torch_mod.as_tensor(holder, device="cuda:%d" % self.hip_device)
+        return int(t.sum().item())
 
     def fetch_qdp(self, tl):
         n, q = self.mine.size, self.qsize
