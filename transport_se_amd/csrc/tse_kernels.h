@@ -484,12 +484,29 @@ struct RemapLds {
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
 };
-__device__ __forceinline__ double ppm_dma(const double* d /* dx1..3 */, double am, double a0, double ap) {
-  double da = d[0] * (d[1] * (ap - a0) + d[2] * (a0 - am));
+__device__ __forceinline__ double ppm_dma(double d0, double d1, double d2, double am, double a0, double ap) {
+  double da = d0 * (d1 * (ap - a0) + d2 * (a0 - am));
   double m = fmin(fabs(da), fmin(2. * fabs(a0 - am), 2. * fabs(ap - a0)));
   double r = copysign(m, da);
   if ((ap - a0) * (a0 - am) <= 0.) r = 0.;
   return r;
+}
+__device__ __forceinline__ double remap_dma_at(const RemapLds& S, int j, int p, double am, double a0, double ap) {
+  return ppm_dma(S.ppmdx[j][0][p], S.ppmdx[j][1][p], S.ppmdx[j][2][p], am, a0, ap);
+}
+__device__ __forceinline__ double remap_ai_at(const RemapLds& S, int j, int p, double aj, double ajp, double dmajp, double dmaj) {
+  return aj + S.ppmdx[j][3][p] * (ajp - aj) +
+         S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (S.ppmdx[j][6][p] - S.ppmdx[j][7][p]) * (ajp - aj) -
+                             S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
+}
+// limited parabola of one cell from its mean a0 and interface values (compute_ppm stage 3, :309-331)
+__device__ __forceinline__ void remap_coefs(double al, double ar, double a0, double& c0, double& c1, double& c2) {
+  if ((ar - a0) * (a0 - al) <= 0.) { al = a0; ar = a0; }
+  if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) * (1.0 / 6.0)) al = 3. * a0 - 2. * ar;
+  if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) * (1.0 / 6.0)) ar = 3. * a0 - 2. * al;
+  c0 = 1.5 * a0 - (al + ar) / 4.;
+  c1 = ar - al;
+  c2 = -6. * a0 + 3. * (al + ar);
 }
 __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
                                                          const double* __restrict__ hybi, const double* __restrict__ dp,
@@ -555,66 +572,49 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
   }
   __syncthreads();
   // ---- phase 2: data part (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209)
+  // Plain straight-line code on purpose: lambdas/arrays passed by pointer ended up in scratch memory inside this loop.
   const int p = tid & 15;
   for (int q = tid >> 4; q < qsize; q += REMAP_THREADS / 16) {
     double* col = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
-    // Cells are consumed strictly in order 1,2,3,...; a register FIFO keeps REMAP_PF column loads in flight per thread
-    // (one thread streams one column: without it only a single 8-byte load per lane would be outstanding).
+    // Cells are consumed strictly in order 1,2,3,...; a register FIFO keeps REMAP_PF column loads in flight per thread.
     int R = 0;                                   // highest cell consumed so far (ghost cells continue past NLEV)
     double pf[REMAP_PF];
 #pragma unroll
     for (int t = 0; t < REMAP_PF; t++) pf[t] = col[(size_t)t * 16];
     double pm1 = 0, pa1 = 0, pm2 = 0, pa2 = 0;   // the last two real cells (mass, mean) for the bottom mirror
-    auto read_next = [&](double& m, double& a) {
-      R++;
-      if (R <= NLEV) {
-        m = pf[0];
-#pragma unroll
-        for (int t = 0; t + 1 < REMAP_PF; t++) pf[t] = pf[t + 1];
-        if (R + REMAP_PF <= NLEV) pf[REMAP_PF - 1] = col[(size_t)(R + REMAP_PF - 1) * 16];
-        a = m * S.rdpo[R + 1][p];
-        pm2 = pm1; pa2 = pa1; pm1 = m; pa1 = a;
-      } else if (R == NLEV + 1) { m = pm1; a = pa1; }   // a(nlev+1) = a(nlev)
-      else { m = pm2; a = pa2; }                         // a(nlev+2) = a(nlev-1)
-    };
-    auto dma_at = [&](int j, double am, double a0_, double ap) {
-      double d[3] = {S.ppmdx[j][0][p], S.ppmdx[j][1][p], S.ppmdx[j][2][p]};
-      return ppm_dma(d, am, a0_, ap);
-    };
-    auto ai_at = [&](int j, double aj, double ajp, double dmajp, double dmaj) {
-      return aj + S.ppmdx[j][3][p] * (ajp - aj) +
-             S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (S.ppmdx[j][6][p] - S.ppmdx[j][7][p]) * (ajp - aj) -
-                                 S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
-    };
+#define TSE_READ_NEXT(m_, a_)                                                            \
+    do {                                                                                 \
+      R++;                                                                               \
+      if (R <= NLEV) {                                                                   \
+        m_ = pf[0];                                                                      \
+        _Pragma("unroll") for (int t = 0; t + 1 < REMAP_PF; t++) pf[t] = pf[t + 1];      \
+        if (R + REMAP_PF <= NLEV) pf[REMAP_PF - 1] = col[(size_t)(R + REMAP_PF - 1) * 16]; \
+        a_ = m_ * S.rdpo[R + 1][p];                                                      \
+        pm2 = pm1; pa2 = pa1; pm1 = m_; pa1 = a_;                                        \
+      } else if (R == NLEV + 1) { m_ = pm1; a_ = pa1; } /* a(nlev+1) = a(nlev)   */      \
+      else { m_ = pm2; a_ = pa2; }                      /* a(nlev+2) = a(nlev-1) */      \
+    } while (0)
     double m1, a1, m2, a2, m3, a3;
-    read_next(m1, a1); read_next(m2, a2); read_next(m3, a3);
+    TSE_READ_NEXT(m1, a1); TSE_READ_NEXT(m2, a2); TSE_READ_NEXT(m3, a3);
     int kk = 1;
     double am2 = a2, am1 = a1, a0 = a1, ap1 = a2, ap2 = a3;  // a(-1)=a(2), a(0)=a(1)
     double m0 = m1, mp1 = m2, mp2 = m3;
-    double dma_m1 = dma_at(0, am2, am1, a0), dma_0 = dma_at(1, am1, a0, ap1), dma_p1 = dma_at(2, a0, ap1, ap2);
-    double ai_m1 = ai_at(0, am1, a0, dma_0, dma_m1), ai_0 = ai_at(1, a0, ap1, dma_p1, dma_0);
+    double dma_m1 = remap_dma_at(S, 0, p, am2, am1, a0), dma_0 = remap_dma_at(S, 1, p, am1, a0, ap1),
+           dma_p1 = remap_dma_at(S, 2, p, a0, ap1, ap2);
+    double ai_m1 = remap_ai_at(S, 0, p, am1, a0, dma_0, dma_m1), ai_0 = remap_ai_at(S, 1, p, a0, ap1, dma_p1, dma_0);
     double masso_kk = 0.0, massn1 = 0.0;
     double c0, c1, c2;
-    auto make_coefs = [&]() {
-      double al = ai_m1, ar = ai_0;
-      if ((ar - a0) * (a0 - al) <= 0.) { al = a0; ar = a0; }
-      if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) * (1.0 / 6.0)) al = 3. * a0 - 2. * ar;
-      if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) * (1.0 / 6.0)) ar = 3. * a0 - 2. * al;
-      c0 = 1.5 * a0 - (al + ar) / 4.;
-      c1 = ar - al;
-      c2 = -6. * a0 + 3. * (al + ar);
-    };
-    make_coefs();
+    remap_coefs(ai_m1, ai_0, a0, c0, c1, c2);
     for (int k = 1; k <= NLEV; k++) {
       const int kt = S.kid[k - 1][p];
       while (kk < kt) {
         masso_kk = masso_kk + m0;
         am2 = am1; am1 = a0; a0 = ap1; ap1 = ap2; m0 = mp1; mp1 = mp2;
-        read_next(mp2, ap2);
+        TSE_READ_NEXT(mp2, ap2);
         kk++;
-        dma_m1 = dma_0; dma_0 = dma_p1; dma_p1 = dma_at(kk + 1, a0, ap1, ap2);
-        ai_m1 = ai_0; ai_0 = ai_at(kk, a0, ap1, dma_p1, dma_0);
-        make_coefs();
+        dma_m1 = dma_0; dma_0 = dma_p1; dma_p1 = remap_dma_at(S, kk + 1, p, a0, ap1, ap2);
+        ai_m1 = ai_0; ai_0 = remap_ai_at(S, kk, p, a0, ap1, dma_p1, dma_0);
+        remap_coefs(ai_m1, ai_0, a0, c0, c1, c2);
       }
       const double x1 = -0.5, x2 = S.z2[k - 1][p];
       double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) * 0.5 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) * (1.0 / 3.0);
@@ -622,6 +622,7 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
       col[(size_t)(k - 1) * 16] = massn2 - massn1;
       massn1 = massn2;
     }
+#undef TSE_READ_NEXT
   }
 }
 
