@@ -81,17 +81,25 @@ int main(int argc, char** argv) {
       int cpt[4] = {0, 3, 15, 12}, cd[4] = {4, 5, 7, 6}, cop[4] = {15, 12, 0, 3};
       for (int t = 0; t < 4; t++) { int p = cpt[t]; tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = make_int2(nb[cd[t]], cop[t]); }
     }
+    // same table but every source redirected to the element itself (gathers hit L1/L2: isolates issue/TA cost)
+    std::vector<int2> tabs = tab;
+    for (size_t i = 0; i < tabs.size(); i++) if (tabs[i].x >= 0) tabs[i].x = (int)(i / 48);
+    int2* dtabs; CK(hipMalloc(&dtabs, tabs.size() * 8)); CK(hipMemcpy(dtabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
     int2 *dtab, *dtab0; CK(hipMalloc(&dtab, tab.size() * 8)); CK(hipMalloc(&dtab0, tab.size() * 8));
     CK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dtab0, tab0.data(), tab.size() * 8, hipMemcpyHostToDevice));
     double* out; CK(hipMalloc(&out, trc * 8));
+    std::vector<int> ho(nelem); for (int e = 0; e < nelem; e++) ho[e] = e;
+    int* dorder; CK(hipMalloc(&dorder, nelem * 4)); CK(hipMemcpy(dorder, ho.data(), nelem * 4, hipMemcpyHostToDevice));
     for (int qb : {1, 5, 35}) {
       int nqc = (qsize + qb - 1) / qb;
       dim3 grid(8 * ((nelem + 7) / 8) * nqc);
       char nm[64];
       snprintf(nm, 64, "k_dss_t<0> qb=%d nogather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0); });
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
+      snprintf(nm, 64, "k_dss_t<0> qb=%d selfgather", qb);
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtabs, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
       snprintf(nm, 64, "k_dss_t<0> qb=%d gather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0); });
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
     }
     int nq = qsize * NLEV, nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
     timeit("k_dss<0> old gather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });

@@ -42,7 +42,7 @@ struct tse_ctx {
   double *Dinv = nullptr, *metdet = nullptr, *rmetdet = nullptr, *spheremp = nullptr, *rspheremp = nullptr;
   double *hyai = nullptr, *hybi = nullptr, *dp0 = nullptr;
   int2 *dss_tab = nullptr, *send_src = nullptr;
-  int *nbr = nullptr;
+  int *nbr = nullptr, *order = nullptr;
   // state
   double *qdp = nullptr, *T = nullptr, *B = nullptr;
   double *vn0 = nullptr, *dp = nullptr, *divdp = nullptr, *divdp_proj = nullptr, *eta = nullptr, *omega_p = nullptr;
@@ -219,6 +219,35 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
     }
   }
   if (upload(&c->dss_tab, tab) || upload(&c->nbr, nbr) || upload(&c->send_src, send_src)) return 1;
+  {
+    // Walk order for the gather kernels.  Each XCD processes a contiguous range of elements (L2 is per XCD); inside
+    // the range we follow a greedy neighbour walk over the local element graph (west/east/south/north links) in
+    // strips, so that the elements whose edge values a block gathers were touched by the same XCD a few blocks
+    // earlier instead of a whole row of the face earlier.  Pure scheduling: results do not depend on it.
+    const int S8 = (n + 7) / 8;
+    std::vector<int> order(n);
+    const int W = getenv("TSE_DSS_STRIP") ? atoi(getenv("TSE_DSS_STRIP")) : 8;
+    for (int x = 0; x < 8; x++) {
+      const int lo = x * S8, hi = std::min(n, lo + S8);
+      if (lo >= hi) continue;
+      std::vector<char> used(hi - lo, 0);
+      int pos = lo;
+      auto in = [&](int e) { return e >= lo && e < hi && !used[e - lo]; };
+      for (int seed = lo; seed < hi; seed++) {
+        if (used[seed - lo]) continue;
+        // strip: from `seed` go east up to W elements (row segment), then continue with the northern neighbours' segment
+        int rowstart = seed;
+        while (rowstart >= 0 && in(rowstart)) {
+          int e = rowstart, cnt = 0, first = e;
+          while (e >= 0 && in(e) && cnt < W) { used[e - lo] = 1; order[pos++] = e; cnt++; int ee = nbr[e * 8 + 1]; e = ee; }
+          int nn = nbr[first * 8 + 3];   // north of the segment's first element
+          rowstart = nn;
+        }
+      }
+    }
+    if (W <= 0) for (int e = 0; e < n; e++) order[e] = e;
+    if (upload(&c->order, order)) return 1;
+  }
 
   // ---- state -------------------------------------------------------------------------------------
   const size_t lev = c->lev(), trc = c->trc();
@@ -253,7 +282,7 @@ void tse_finalize(tse_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
-                  c->lvl_tmp, c->lvl_tmp2, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+                  c->lvl_tmp, c->lvl_tmp2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
   resolve_timers(c);
@@ -400,17 +429,20 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     Scope s(c, "dss");
     const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
     const dim3 grid(8 * ((c->nelemd + 7) / 8) * nqc);
+    const int npair = (c->nelemd + 1) / 2;
+    const dim3 grid2(8 * ((npair + 7) / 8) * nqc);
+    // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: (qsize*72 + 72) always is
     if (Qn0_avg)
-      hipLaunchKernelGGL(k_dss_t<1>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV, DssExtra{});
+      hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                         Qn0_avg, c->recvbuf, nq + NLEV, c->order);
     else if (mode3) {
       DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = rdt; X.dp = c->dp; X.divdp_proj = c->divdp_proj; X.qmin = c->qmin; X.qmax = c->qmax;
       X.lapout = c->B;
       hipLaunchKernelGGL(k_dss_t<3>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, X);
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, X, c->order);
     } else
-      hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, DssExtra{});
+      hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order);
     LAUNCH_CHECK();
   }
   if (var) {
@@ -476,10 +508,11 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       if (fused) {  // DSS + inverse mass + second Laplacian + biharmonic scaling in one pass: T = biharmonic term
         DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = dt; X.nu_q = c->nu_q; X.dp0 = c->dp0;
         hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
-                           (const double*)nullptr, c->recvbuf, nq, X);
+                           (const double*)nullptr, c->recvbuf, nq, X, c->order);
       } else {
-        hipLaunchKernelGGL(k_dss_t<0>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
-                           (const double*)nullptr, c->recvbuf, nq, DssExtra{});
+        const int npair = (c->nelemd + 1) / 2;
+        hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * ((npair + 7) / 8) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
+                           c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order);
       }
       LAUNCH_CHECK();
     }

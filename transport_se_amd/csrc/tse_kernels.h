@@ -338,11 +338,13 @@ template <int MODE>
 __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
                                                         const double* __restrict__ rspheremp, const double* __restrict__ src,
                                                         double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                        const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X) {
+                                                        const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X,
+                                                        const int* __restrict__ order) {
   const int S8 = (nelemd + 7) >> 3;
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
-  const int e = xcd * S8 + it % S8, qc = it / S8;
-  if (e >= nelemd) return;
+  const int slot = xcd * S8 + it % S8, qc = it / S8;
+  if (slot >= nelemd) return;
+  const int e = order[slot];   // walk order inside the XCD's element range: neighbours close in time (tse_api.hip)
   const int tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
   // Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take up to 3 contributions
   // (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot re-reads the
@@ -430,6 +432,78 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
         if (j == 0) { X.qmin[((size_t)e * qsize + q) * NLEV + k] = mn; X.qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
       }
     }
+  }
+}
+
+// Default tracer DSS: as k_dss_t<0|1>, but every lane handles TWO consecutive levels, so that each own/neighbour access is
+// a 16-byte load (the level-fastest source makes the level pair contiguous).  The 8-byte version spent as much time
+// issuing the 12 loads per tracer as moving the data (a variant whose gathers all hit the lane's own element in L1 was
+// as slow as the real one).  Block = 2 elements x 36 level pairs x 4 rows = 288 threads.
+constexpr int DSS2_THREADS = 320;
+template <int MODE>
+__global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
+                                                         const double* __restrict__ rspheremp, const double* __restrict__ src,
+                                                         double* __restrict__ dst, const double* __restrict__ Qn0,
+                                                         const double* __restrict__ recvbuf, int nlyr_halo,
+                                                         const int* __restrict__ order) {
+  const int npair = (nelemd + 1) >> 1;               // element pairs
+  const int S8 = (npair + 7) >> 3;
+  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
+  const int pslot = xcd * S8 + it % S8, qc = it / S8;
+  const int tid = threadIdx.x;
+  const int el = tid / 144, r = tid % 144;
+  const int slot = pslot * 2 + el;
+  if (pslot >= npair || slot >= nelemd || tid >= 288) return;
+  const int e = order[slot];
+  const int k0 = (r >> 2) * 2, j = r & 3;            // levels k0, k0+1
+  constexpr int NS = 8;
+  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
+  const double* gp[NS];
+  unsigned gvalid = 0, gremote = 0;
+  const int q0 = qc * qb;
+  const double* own0 = src + (((size_t)e * qsize + q0) * 16 + j * 4) * NLEV + k0;
+  int2 tt[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int2 t = tt[s];
+    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + k0; gvalid |= 1u << s; }
+    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + k0; gvalid |= 1u << s; gremote |= 1u << s; }
+    else gp[s] = own0;
+  }
+  double rs[4];
+  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  const int q1 = min(qsize, (qc + 1) * qb);
+  for (int q = q0; q < q1; q++) {
+    const size_t dq = (size_t)(q - q0);
+    double2 v[4], a[NS];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * 16 * NLEV + (size_t)i * NLEV);
+#pragma unroll
+    for (int s = 0; s < NS; s++) a[s] = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+      if (gvalid & (1u << s)) a[s] = *reinterpret_cast<const double2*>(gp[s] + dq * ((gremote & (1u << s)) ? NLEV : 16 * NLEV));
+    // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
+#define ADD2(vi, as) do { vi.x = vi.x + as.x; vi.y = vi.y + as.y; } while (0)
+    ADD2(v[0], a[0]); ADD2(v[0], a[1]); ADD2(v[0], a[2]);
+    ADD2(v[1], a[3]);
+    ADD2(v[2], a[4]);
+    ADD2(v[3], a[5]); ADD2(v[3], a[6]); ADD2(v[3], a[7]);
+#undef ADD2
+    double o0[4], o1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o0[i] = rs[i] * v[i].x; o1[i] = rs[i] * v[i].y; }
+    const size_t off = (((size_t)e * qsize + q) * NLEV + k0) * 16 + j * 4;
+    if (MODE == 1) {
+      double q0v[4], q1v[4];
+      load4(Qn0 + off, q0v); load4(Qn0 + off + 16, q1v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) { o0[i] = (q0v[i] + 2 * o0[i]) / 3; o1[i] = (q1v[i] + 2 * o1[i]) / 3; }
+    }
+    store4(dst + off, o0);
+    store4(dst + off + 16, o1);
   }
 }
 
