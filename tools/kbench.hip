@@ -101,6 +101,26 @@ int main(int argc, char** argv) {
       snprintf(nm, 64, "k_dss_t<0> qb=%d gather", qb);
       timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
     }
+    {   // overlap experiment: VALU-bound advance and memory-bound DSS on two streams, each on half of the tracers' worth of elements
+      hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
+      int npair = (nelem + 1) / 2, nqc = (qsize + 4) / 5;
+      dim3 g2(8 * ((npair + 7) / 8) * nqc);
+      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(nelem), dim3(SLAB_THREADS), 0, st, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); };
+      auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder); };
+      timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });
+      timeit("adv<1> then dss (serial)", 4 * fb, [&] { adv(0); dss(0); });
+      // concurrent: note they touch the same T (race is irrelevant for timing)
+      CK(hipDeviceSynchronize());
+      hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+      for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0, 0)); CK(hipStreamWaitEvent(s1, e0, 0)); CK(hipStreamWaitEvent(s2, e0, 0));
+        for (int r = 0; r < 3; r++) { adv(s1); dss(s2); }
+        CK(hipEventRecord(e1, s1)); CK(hipEventRecord(e2, s2)); CK(hipStreamWaitEvent(0, e1, 0)); CK(hipStreamWaitEvent(0, e2, 0));
+        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, e0, b));
+        if (rep == 1) printf("%-28s %8.3f ms per (adv+dss) pair\n", "adv<1> || dss (2 streams)", ms / 3);
+      }
+    }
     int nq = qsize * NLEV, nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
     timeit("k_dss<0> old gather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });
     timeit("k_dss<0> old nogather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });

@@ -49,6 +49,7 @@ struct tse_ctx {
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
   int* bad = nullptr;
+  int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
   // halo
   int ncol_send = 0, ncol_recv = 0, nlyr_halo = 0;
   double *sendbuf = nullptr, *recvbuf = nullptr;
@@ -297,6 +298,7 @@ int tse_halo_layout(tse_ctx* c, int* ns, int* nr) { if (ns) *ns = c->ncol_send; 
 
 // ---- host <-> device copies ---------------------------------------------------------------------
 int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, int nt) {
+  c->mm_valid = 0;
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_h2d: nt=%d qsize_d=%d", nt, qsize_d);
   const size_t per = (size_t)c->qsize * NLEV * 16;
   c->hstage.resize((size_t)c->nelemd * per);
@@ -336,6 +338,7 @@ int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, 
                     const double* omega_p, size_t s3) {
   // vn0(np,np,2,nlev) in Fortran memory is [k][c][p]: the device layout
   if (put_level(c, c->vn0, vn0, s0, 2 * NLEV * 16, 2 * NLEV * 16)) return 1;
+  if (dp) c->mm_valid = 0;   // bounds were formed with the previous dp
   if (put_level(c, c->dp, dp, s1, NLEV * 16, NLEV * 16)) return 1;
   if (put_level(c, c->eta, eta, s2, NLEVP * 16, NLEVP * 16)) return 1;
   if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
@@ -434,7 +437,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: (qsize*72 + 72) always is
     if (Qn0_avg)
       hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV, c->order);
+                         Qn0_avg, c->recvbuf, nq + NLEV, c->order, (const double*)c->dp, c->qmin2, c->qmax2);
     else if (mode3) {
       DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = rdt; X.dp = c->dp; X.divdp_proj = c->divdp_proj; X.qmin = c->qmin; X.qmax = c->qmax;
       X.lapout = c->B;
@@ -442,7 +445,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
                          (const double*)nullptr, c->recvbuf, nq + NLEV, X, c->order);
     } else
       hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order);
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr);
     LAUNCH_CHECK();
   }
   if (var) {
@@ -460,7 +463,8 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
 }
 
 // one RK stage; fuse_avg: apply qdp_time_avg in the final DSS (whole-step path only)
-static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false) {
+static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false,
+                           bool fused_mm = false) {
   if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
@@ -469,11 +473,15 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
   const dim3 grid(c->nelemd), blk(SLAB_THREADS);
   if (rhs == 0) {
-    {
+    if (fused_mm && c->mm_valid == n0_qdp) {
+      // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
+      std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
+    } else {
       Scope s(c, "minmax");
       hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
     }
+    c->mm_valid = 0;
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
@@ -512,7 +520,8 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       } else {
         const int npair = (c->nelemd + 1) / 2;
         hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * ((npair + 7) / 8) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
-                           c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order);
+                           c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order, (const double*)nullptr, (double*)nullptr,
+                           (double*)nullptr);
       }
       LAUNCH_CHECK();
     }
@@ -533,10 +542,12 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
 }
 
 int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
+  c->mm_valid = 0;
   return euler_step_impl(c, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier, false, 0);
 }
 
 int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
+  c->mm_valid = 0;
   Scope s(c, "avg");
   size_t n = c->trc();
   hipLaunchKernelGGL(k_time_avg, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
@@ -549,9 +560,10 @@ int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) 
   if (n0_qdp == np1_qdp) return fail("advec_tracers_remap_rk2: n0_qdp == np1_qdp");
   if (tse_compute_divdp(c)) return 1;
   const bool f = fuse_stage3();
-  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f)) return 1;
+  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f, true)) return 1;
   if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, f)) return 1;
   if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, f)) return 1;
+  c->mm_valid = np1_qdp;   // the final DSS emitted min/max of Qdp(np1)/dp for the next step
   return 0;
 }
 
@@ -560,12 +572,13 @@ int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
   {
     Scope s(c, "remap");
     hipLaunchKernelGGL(k_remap, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp + (size_t)(np1_qdp - 1) * c->trc(), c->bad);
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp + (size_t)(np1_qdp - 1) * c->trc(), c->bad, c->qmin2, c->qmax2);
     LAUNCH_CHECK();
   }
   int bad = 0;
   HIPCHK(hipMemcpyAsync(&bad, c->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
+  c->mm_valid = bad ? 0 : np1_qdp;   // k_remap emitted the element min/max of the remapped field
   if (bad) {
     HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
     fail("negative layer thickness.  timestep or remap time too large");
@@ -595,6 +608,7 @@ int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, c
   return 0;
 }
 int tse_dcmip_set_initial(tse_ctx* c) {
+  c->mm_valid = 0;
   if (!c->dcmip_test) return fail("tse_dcmip_set_initial: call tse_dcmip_init first");
   Scope s(c, "dcmip");
   size_t tot = c->lev();

@@ -445,7 +445,10 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
                                                          const double* __restrict__ rspheremp, const double* __restrict__ src,
                                                          double* __restrict__ dst, const double* __restrict__ Qn0,
                                                          const double* __restrict__ recvbuf, int nlyr_halo,
-                                                         const int* __restrict__ order) {
+                                                         const int* __restrict__ order, const double* __restrict__ dpnext,
+                                                         double* __restrict__ mn_out, double* __restrict__ mx_out) {
+  // mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
+  // next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
   const int npair = (nelemd + 1) >> 1;               // element pairs
   const int S8 = (npair + 7) >> 3;
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
@@ -474,6 +477,11 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
   }
   double rs[4];
   load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  double dn0[4] = {1, 1, 1, 1}, dn1[4] = {1, 1, 1, 1};
+  if (MODE == 1 && mn_out) {
+    load4(dpnext + ((size_t)e * NLEV + k0) * 16 + j * 4, dn0);
+    load4(dpnext + ((size_t)e * NLEV + k0 + 1) * 16 + j * 4, dn1);
+  }
   const int q1 = min(qsize, (qc + 1) * qb);
   for (int q = q0; q < q1; q++) {
     const size_t dq = (size_t)(q - q0);
@@ -504,6 +512,17 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
     }
     store4(dst + off, o0);
     store4(dst + off + 16, o1);
+    if (MODE == 1 && mn_out) {
+      double x0[4], x1[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { x0[i] = o0[i] / dn0[i]; x1[i] = o1[i] / dn1[i]; }
+      const double mn0 = quad_min(fmin(fmin(x0[0], x0[1]), fmin(x0[2], x0[3]))), mx0 = quad_max(fmax(fmax(x0[0], x0[1]), fmax(x0[2], x0[3])));
+      const double mn1 = quad_min(fmin(fmin(x1[0], x1[1]), fmin(x1[2], x1[3]))), mx1 = quad_max(fmax(fmax(x1[0], x1[1]), fmax(x1[2], x1[3])));
+      if (j == 0) {
+        const size_t mi = ((size_t)e * qsize + q) * NLEV + k0;
+        mn_out[mi] = mn0; mn_out[mi + 1] = mn1; mx_out[mi] = mx0; mx_out[mi + 1] = mx1;
+      }
+    }
   }
 }
 
@@ -554,6 +573,7 @@ struct RemapLds {
   double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
   double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
   double rdpo[NLEV + 4][16];       // 1/dpo (the column loop multiplies instead of dividing)
+  double dpn[NLEV][16];            // derived%dp of the next step (only for the fused min/max emission)
   double z2[NLEV][16];
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
@@ -586,7 +606,8 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
                                                          const double* __restrict__ hybi, const double* __restrict__ dp,
                                                          const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
                                                          double* __restrict__ ps_v, double* __restrict__ Q,
-                                                         int* __restrict__ bad) {
+                                                         int* __restrict__ bad, double* __restrict__ mn_out,
+                                                         double* __restrict__ mx_out) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
   const int e = blockIdx.x, tid = threadIdx.x;
@@ -596,6 +617,7 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
     double d = dp[o] - dt * divdp_proj[o];
     dp3d[o] = d;
     S.dpo[(w >> 4) + 2][w & 15] = d;
+    S.dpn[w >> 4][w & 15] = dp[o];
     if (d < 0) atomicOr(bad, 1);
   }
   __syncthreads();
@@ -693,8 +715,16 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
       const double x1 = -0.5, x2 = S.z2[k - 1][p];
       double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) * 0.5 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) * (1.0 / 3.0);
       double massn2 = masso_kk + integ * S.dpo[kk + 1][p];
-      col[(size_t)(k - 1) * 16] = massn2 - massn1;
+      const double qnew = massn2 - massn1;
+      col[(size_t)(k - 1) * 16] = qnew;
       massn1 = massn2;
+      if (mn_out) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
+        const double x = qnew / S.dpn[k - 1][p];
+        double mn = x, mx = x;
+        mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
+        mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
+        if (p == 0) { mn_out[((size_t)e * qsize + q) * NLEV + k - 1] = mn; mx_out[((size_t)e * qsize + q) * NLEV + k - 1] = mx; }
+      }
     }
 #undef TSE_READ_NEXT
   }
