@@ -42,10 +42,14 @@ extern "C" {
 typedef struct tse_ctx tse_ctx;
 
 /* Exchange callback = the body of bndry_exchangeV (bndry_mod.F90:21-126): send `sendbuf` slot s
- * (send_len[s]*nlyr doubles at column offset send_off[s], layer index fastest) to rank send_peer[s], receive the
+ * (len[s]*nlyr doubles at entry offset sum(len[:s]), layer index fastest) to rank send_peer[s], receive the
  * mirror-image slot into `recvbuf`.  Both pointers are DEVICE pointers.  The library has finished writing
- * sendbuf (stream-synchronised) when it calls this, and reads recvbuf only after it returns. */
-typedef int (*tse_exchange_fn)(void *user, double *sendbuf, double *recvbuf, int nlyr);
+ * sendbuf (stream-synchronised) when it calls this, and reads recvbuf only after it returns.
+ *   kind 0: one entry per edge-buffer column, len[s] = lengthP of the slot (the reference's message layout);
+ *   kind 1: the neighbour min/max exchange (viscosity_mod.F90:748-816): the packed fields are element constants, so one
+ *           entry per neighbouring (element, direction) pair is sent instead of one per column; len[s] = the number of
+ *           shared edges + shared corners with that rank (tse_halo_layout gives the totals). */
+typedef int (*tse_exchange_fn)(void *user, double *sendbuf, double *recvbuf, int nlyr, int kind);
 
 typedef struct {
   int nelemd;          /* elements on this rank */
@@ -126,6 +130,8 @@ void *tse_device_ptr(tse_ctx *ctx, const char *name, size_t *nbytes);
 int tse_kernel_time(tse_ctx *ctx, const char *name, double *ms, long *launches);
 int tse_timing(tse_ctx *ctx, int enable); /* enable/disable + reset per-kernel event timing */
 int tse_halo_layout(tse_ctx *ctx, int *ncol_send, int *ncol_recv);
+/* per-slot entry counts of the kind-1 (min/max) exchange, in send-slot / recv-slot order */
+int tse_halo_minmax_layout(tse_ctx *ctx, int *send_len, int *recv_len);
 
 #ifdef __cplusplus
 }

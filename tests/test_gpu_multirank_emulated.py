@@ -30,25 +30,39 @@ def _run(world):
     result = [None] * world
     errors = []
 
-    def make_exchange(r):
-        d = descs[r]
-        offs = np.concatenate([[0], np.cumsum([s[2] for s in d["send"]])]).astype(int)
+    lens = [dict() for _ in range(world)]   # lens[r][kind] = (send_len per slot, recv_len per slot)
 
-        def exchange(sbuf, rbuf, nlyr):
+    class Exchange:
+        """bndry_exchangeV between the emulated ranks: slot s of rank r <- the matching send slot of its peer"""
+
+        def __init__(self, r):
+            self.r = r
+            d = descs[r]
+            lens[r][0] = ([s[2] for s in d["send"]], [s[2] for s in d["recv"]])
+
+        def set_minmax_layout(self, send_len, recv_len):       # called by HipMod after tse_init
+            lens[self.r][1] = ([int(x) for x in send_len], [int(x) for x in recv_len])
+
+        def __call__(self, sbuf, rbuf, nlyr, kind):
+            r = self.r; d = descs[r]
             bufs[r] = (sbuf, nlyr)
             barrier.wait()
-            for i, (peer, _, ln) in enumerate(d["recv"]):
+            roff = np.concatenate([[0], np.cumsum(lens[r][kind][1])]).astype(int)
+            for i, (peer, _, _) in enumerate(d["recv"]):
                 pd = descs[peer]
-                poffs = np.concatenate([[0], np.cumsum([s[2] for s in pd["send"]])]).astype(int)
                 j = [k for k, s in enumerate(pd["send"]) if s[0] == r][0]
-                assert pd["send"][j][2] == ln and bufs[peer][1] == nlyr
-                src = bufs[peer][0] + int(poffs[j]) * nlyr * 8
-                dst = rbuf + int(offs[i]) * nlyr * 8
+                soff = np.concatenate([[0], np.cumsum(lens[peer][kind][0])]).astype(int)
+                ln = lens[r][kind][1][i]
+                assert lens[peer][kind][0][j] == ln and bufs[peer][1] == nlyr
+                src = bufs[peer][0] + int(soff[j]) * nlyr * 8
+                dst = rbuf + int(roff[i]) * nlyr * 8
                 rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(ln * nlyr * 8), C.c_int(3))
                 assert rc == 0
             barrier.wait()
             return 0
-        return exchange
+
+    def make_exchange(r):
+        return Exchange(r)
 
     def worker(r):
         try:

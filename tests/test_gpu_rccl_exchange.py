@@ -31,5 +31,11 @@ def test_halo_exchange_on_rccl_self_peer():
         assert ex(send.data_ptr(), recv.data_ptr(), nlyr) == 0
         torch.cuda.synchronize()
         assert torch.equal(recv, send)
+        # kind 1 (compact min/max exchange): other slot lengths over the same buffers
+        ex.set_minmax_layout([2, 3], [2, 3])
+        recv.zero_()
+        assert ex(send.data_ptr(), recv.data_ptr(), nlyr, 1) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(recv[:5 * nlyr], send[:5 * nlyr]) and not recv[5 * nlyr:].any()
     finally:
         dist.destroy_process_group()

@@ -8,7 +8,7 @@ SO = os.path.join(HERE, "libtransport_se_hip.so")
 SRC = [os.path.join(HERE, "csrc", f) for f in ("tse_api.hip", "tse_kernels.h", "tse_device.h")]
 HDR = os.path.join(os.path.dirname(HERE), "include", "transport_se_hip.h")
 
-EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
 
 
 class InitArgs(C.Structure):
@@ -45,7 +45,7 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_set_derived", "tse_set_divdp", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
-           "tse_halo_layout"]
+           "tse_halo_layout", "tse_halo_minmax_layout"]
 
 
 def lib():
@@ -81,5 +81,6 @@ def lib():
     L.tse_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(d), C.POINTER(C.c_long)]
     L.tse_timing.argtypes = [vp, i]
     L.tse_halo_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.tse_halo_minmax_layout.argtypes = [vp, vp, vp]
     _lib = L
     return L

@@ -52,6 +52,9 @@ struct tse_ctx {
   int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
   // halo
   int ncol_send = 0, ncol_recv = 0, nlyr_halo = 0;
+  int nmm_send = 0, nmm_recv = 0;              // entries of the compact min/max exchange
+  std::vector<int> mm_send_len, mm_recv_len;   // per slot
+  int2* mm_send_src = nullptr;
   double *sendbuf = nullptr, *recvbuf = nullptr;
   bool own_halo = false;
   tse_exchange_fn exchange = nullptr; void* exchange_user = nullptr;
@@ -161,10 +164,12 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   for (int s = 0; s < a->nsend; s++) maxcol = std::max(maxcol, a->send_ptrP[s] - 1 + a->send_lengthP[s]);
   for (int s = 0; s < a->nrecv; s++) maxcol = std::max(maxcol, a->recv_ptrP[s] - 1 + a->recv_lengthP[s]);
   std::vector<int> own_e(maxcol, -1), own_p(maxcol, -1), send_idx(maxcol, -1), recv_idx(maxcol, -1);
+  std::vector<int> put_start(maxcol, -1), get_start(maxcol, 0), mm_recv_idx(maxcol, -1);   // first column of an edge/corner -> element
   for (int e = 0; e < n; e++)
     for (int d = 0; d < 8; d++) {
       int pm = a->putmapP[e * 8 + d];
       if (pm < 0) continue;
+      put_start[pm] = e;
       if (d < 4) {
         for (int k = 0; k < 4; k++) {  // reversal is applied at pack time (edge_mod.F90:443-485)
           int col = pm + (a->reverse[e * 8 + d] ? 3 - k : k);
@@ -178,6 +183,28 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   c->ncol_recv = 0;
   for (int s = 0; s < a->nrecv; s++)
     for (int i = 0; i < a->recv_lengthP[s]; i++) recv_idx[a->recv_ptrP[s] - 1 + i] = c->ncol_recv++;
+  // compact min/max exchange: one entry per (element, direction) pair that crosses the rank boundary.  Sender and
+  // receiver enumerate the edge/corner start columns of a slot in increasing column order, which is the same sequence
+  // on both ranks because the two slots are mirror images (the sender writes where the receiver reads).
+  for (int i = 0; i < n * 8; i++) if (a->getmapP[i] >= 0) get_start[a->getmapP[i]] = 1;
+  std::vector<int2> mm_src;
+  for (int s = 0; s < a->nsend; s++) {
+    int cnt = 0;
+    for (int i = 0; i < a->send_lengthP[s]; i++) {
+      int col = a->send_ptrP[s] - 1 + i;
+      if (put_start[col] >= 0) { mm_src.push_back(make_int2(put_start[col], 0)); cnt++; }
+    }
+    c->mm_send_len.push_back(cnt);
+  }
+  c->nmm_send = (int)mm_src.size();
+  for (int s = 0; s < a->nrecv; s++) {
+    int cnt = 0;
+    for (int i = 0; i < a->recv_lengthP[s]; i++) {
+      int col = a->recv_ptrP[s] - 1 + i;
+      if (get_start[col]) { mm_recv_idx[col] = c->nmm_recv++; cnt++; }
+    }
+    c->mm_recv_len.push_back(cnt);
+  }
   if ((c->ncol_send || c->ncol_recv) && !a->exchange) { return fail("tse_init: neighbour-rank slots given but no exchange callback"); }
 
   std::vector<int2> send_src(c->ncol_send);
@@ -206,7 +233,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
         if (source_of(gm + k, s)) return fail("tse_init: element %d edge %d reads column %d that nobody writes", e, d, gm + k);
         int p = edge_point(d, k);
         tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = s;
-        if (k == 0) nbr[e * 8 + d] = s.x;  // element-constant min/max: any column of the edge will do
+        if (k == 0) nbr[e * 8 + d] = s.x >= 0 ? s.x : -(mm_recv_idx[gm] + 2);  // remote: entry of the compact min/max exchange
       }
     }
     for (int t = 0; t < 4; t++) {
@@ -216,10 +243,10 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
       if (source_of(gm, s)) return fail("tse_init: element %d corner %d reads column %d that nobody writes", e, d, gm);
       int p = corner_point(d);
       tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = s;
-      nbr[e * 8 + d] = s.x;
+      nbr[e * 8 + d] = s.x >= 0 ? s.x : -(mm_recv_idx[gm] + 2);
     }
   }
-  if (upload(&c->dss_tab, tab) || upload(&c->nbr, nbr) || upload(&c->send_src, send_src)) return 1;
+  if (upload(&c->dss_tab, tab) || upload(&c->nbr, nbr) || upload(&c->send_src, send_src) || upload(&c->mm_send_src, mm_src)) return 1;
   {
     // Walk order for the gather kernels.  Each XCD processes a contiguous range of elements (L2 is per XCD); inside
     // the range we follow a greedy neighbour walk over the local element graph (west/east/south/north links) in
@@ -282,7 +309,7 @@ void tse_finalize(tse_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
-                  c->nbr, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
+                  c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->lvl_tmp2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
@@ -295,6 +322,11 @@ void tse_finalize(tse_ctx* c) {
 int tse_synchronize(tse_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
 
 int tse_halo_layout(tse_ctx* c, int* ns, int* nr) { if (ns) *ns = c->ncol_send; if (nr) *nr = c->ncol_recv; return 0; }
+int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
+  for (size_t i = 0; i < c->mm_send_len.size(); i++) send_len[i] = c->mm_send_len[i];
+  for (size_t i = 0; i < c->mm_recv_len.size(); i++) recv_len[i] = c->mm_recv_len[i];
+  return 0;
+}
 
 // ---- host <-> device copies ---------------------------------------------------------------------
 int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, int nt) {
@@ -378,23 +410,23 @@ int tse_compute_divdp(tse_ctx* c) {
 }
 
 // bndry_exchangeV on the packed rank-boundary columns (no-op on one rank)
-static int halo_exchange(tse_ctx* c, int nlyr) {
+static int halo_exchange(tse_ctx* c, int nlyr, int kind = 0) {
   if (!c->ncol_send && !c->ncol_recv) return 0;
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->exchange(c->exchange_user, c->sendbuf, c->recvbuf, nlyr)) return fail("exchange callback failed");
+  if (c->exchange(c->exchange_user, c->sendbuf, c->recvbuf, nlyr, kind)) return fail("exchange callback failed");
   return 0;
 }
 
 // min/max over neighbours of qmin/qmax (in place; double-buffered on the device)
 static int neighbor_minmax(tse_ctx* c) {
   const int m = c->qsize * NLEV;
-  if (c->ncol_send) {
-    size_t tot = (size_t)c->ncol_send * m;
-    hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, m, c->send_src,
+  if (c->nmm_send) {
+    size_t tot = (size_t)c->nmm_send * m;
+    hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nmm_send, m, c->mm_send_src,
                        c->qmin, c->qmax, c->sendbuf, 2 * m, 0);
     LAUNCH_CHECK();
   }
-  if (halo_exchange(c, 2 * m)) return 1;
+  if (halo_exchange(c, 2 * m, 1)) return 1;
   {
     Scope s(c, "minmax");
     hipLaunchKernelGGL(k_nbr_minmax, dim3(8 * ((c->nelemd + 7) / 8)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,

@@ -33,8 +33,11 @@ class HaloExchange:
         several ranks share one GPU for rehearsals; the production path sends the device buffers with RCCL."""
         self.sched, self.dist, self.torch, self.device = sched, dist_mod, torch_mod, device
         self.stage = stage_through_host
-        self.off_s = np.concatenate([[0], np.cumsum([s[2] for s in sched["send"]])]).astype(int)
-        self.off_r = np.concatenate([[0], np.cumsum([s[2] for s in sched["recv"]])]).astype(int)
+        self.len_s = {0: [int(s[2]) for s in sched["send"]]}; self.len_r = {0: [int(s[2]) for s in sched["recv"]]}
+
+    def set_minmax_layout(self, send_len, recv_len):
+        """per-slot entry counts of the compact neighbour min/max exchange (kind 1), from tse_halo_minmax_layout"""
+        self.len_s[1] = [int(x) for x in send_len]; self.len_r[1] = [int(x) for x in recv_len]
 
     def _wrap(self, ptr, count):
         if str(self.device) == "cpu":
@@ -45,19 +48,23 @@ class HaloExchange:
         holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
         return self.torch.as_tensor(holder, device=self.device)
 
-    def __call__(self, sbuf, rbuf, nlyr):
+    def __call__(self, sbuf, rbuf, nlyr, kind=0):
         torch, dist = self.torch, self.dist
-        ns, nr = int(self.off_s[-1]), int(self.off_r[-1])
+        ls, lr = self.len_s[kind], self.len_r[kind]
+        off_s = np.concatenate([[0], np.cumsum(ls)]).astype(int); off_r = np.concatenate([[0], np.cumsum(lr)]).astype(int)
+        ns, nr = int(off_s[-1]), int(off_r[-1])
         st = self._wrap(sbuf, ns * nlyr); rt = self._wrap(rbuf, nr * nlyr)
         rt_dev = None
         if self.stage and str(self.device) != "cpu":
             rt_dev = rt
             st = st.cpu(); rt = torch.empty(nr * nlyr, dtype=torch.float64)
         ops = []
-        for i, (peer, _, ln) in enumerate(self.sched["recv"]):
-            ops.append(dist.P2POp(dist.irecv, rt[self.off_r[i] * nlyr:(self.off_r[i] + ln) * nlyr], int(peer)))
-        for i, (peer, _, ln) in enumerate(self.sched["send"]):
-            ops.append(dist.P2POp(dist.isend, st[self.off_s[i] * nlyr:(self.off_s[i] + ln) * nlyr], int(peer)))
+        for i, (peer, _, _) in enumerate(self.sched["recv"]):
+            if lr[i]:
+                ops.append(dist.P2POp(dist.irecv, rt[off_r[i] * nlyr:(off_r[i] + lr[i]) * nlyr], int(peer)))
+        for i, (peer, _, _) in enumerate(self.sched["send"]):
+            if ls[i]:
+                ops.append(dist.P2POp(dist.isend, st[off_s[i] * nlyr:(off_s[i] + ls[i]) * nlyr], int(peer)))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
         if rt_dev is not None:

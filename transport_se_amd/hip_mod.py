@@ -34,7 +34,7 @@ class HipMod:
     def __init__(self, elem, deriv_Dvv, hvcoord, qsize, nu_q, limiter_option=8, rsplit=3, device=-1,
                  schedule=None, exchange=None):
         """cuda_mod_init.  hvcoord = (hyai, hybi, ps0).  schedule = dict(send=[(peer, ptrP, lengthP)...],
-        recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr) -> 0."""
+        recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr, kind) -> 0."""
         L = _lib.lib()
         self.L = L
         self.qsize = int(qsize)
@@ -63,9 +63,9 @@ class HipMod:
                 setattr(a, "%s_%s" % (side, nm), _vp(keep(cyc[:, col], np.int32)))
         self.schedule = sched
         if exchange is not None:
-            def _cb(user, sbuf, rbuf, nlyr):
+            def _cb(user, sbuf, rbuf, nlyr, kind):
                 try:
-                    return int(exchange(sbuf, rbuf, nlyr) or 0)
+                    return int(exchange(sbuf, rbuf, nlyr, kind) or 0)
                 except Exception as ex:  # noqa: BLE001
                     print("exchange callback failed:", ex)
                     return 1
@@ -74,6 +74,13 @@ class HipMod:
         h = C.c_void_p()
         self._chk(L.tse_init(C.byref(h), C.byref(a)))
         self.h = h
+        # per-slot entry counts of the compact (kind 1) min/max exchange, for the exchange object
+        ns, nr = len(sched["send"]), len(sched["recv"])
+        sl = np.zeros(max(ns, 1), dtype=np.int32); rl = np.zeros(max(nr, 1), dtype=np.int32)
+        L.tse_halo_minmax_layout(self.h, _vp(sl), _vp(rl))
+        self.minmax_send_len, self.minmax_recv_len = sl[:ns].copy(), rl[:nr].copy()
+        if exchange is not None and hasattr(exchange, "set_minmax_layout"):
+            exchange.set_minmax_layout(self.minmax_send_len, self.minmax_recv_len)
 
     def _chk(self, rc):
         if rc:
