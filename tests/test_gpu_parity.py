@@ -179,3 +179,20 @@ def test_many_tracers_qsize_40():
     hip.copy_qdp_d2h(elem, 2)
     assert relerr(elem["Qdp"][:, 1], o.qdp[1]) < 6 * TOL_STEP
     hip.close(); o.close()
+
+
+@pytest.mark.parametrize("ne,qsize", [(3, 1), (2, 2)])
+def test_ragged_sizes(ne, qsize):
+    """element counts that are not multiples of 8 (ne=3: 54 elements -> ragged XCD ranges and an odd element pair count)
+    and a single tracer: device-resident run vs oracle"""
+    o = po.Oracle(ne, qsize, nu_q=2e18)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+    o.dcmip_init(1)
+    assert hip.prim_run_subcycle(900.0, 2, 0) == 6
+    done, _ = o.prim_run(1, 900.0, 2)
+    assert done == 6
+    hip.copy_qdp_d2h(elem, 1)
+    assert relerr(elem["Qdp"][:, 0], o.qdp[0]) < 10 * TOL_STEP
+    hip.close(); o.close()
