@@ -25,6 +25,7 @@ module cuda_mod
   use schedtype_mod,  only : schedule
   implicit none
   private
+#include <mpif.h>
   public :: cuda_mod_init, euler_step_cuda, qdp_time_avg_cuda, vertical_remap_cuda, copy_qdp_d2h, copy_qdp_h2d
 
   ! mirror of tse_init_args (include/transport_se_hip.h)
@@ -76,12 +77,26 @@ module cuda_mod
      function tse_last_error() bind(C, name='tse_last_error') result(p)
        import; type(c_ptr) :: p
      end function
+     integer(c_int) function tse_halo_layout(ctx, ns, nr) bind(C, name='tse_halo_layout')
+       import; type(c_ptr), value :: ctx; integer(c_int), intent(out) :: ns, nr
+     end function
+     integer(c_int) function tse_halo_minmax_layout(ctx, sl, rl) bind(C, name='tse_halo_minmax_layout')
+       import; type(c_ptr), value :: ctx, sl, rl
+     end function
+     ! HIP runtime (libamdhip64): staging copies of the packed slots for a non-GPU-aware MPI
+     integer(c_int) function hipMemcpy(dst, src, nbytes, kind) bind(C, name='hipMemcpy')
+       import; type(c_ptr), value :: dst, src; integer(c_size_t), value :: nbytes; integer(c_int), value :: kind
+     end function
   end interface
 
   type(c_ptr), save :: ctx = c_null_ptr
   integer(c_int), allocatable, target, save :: putm(:,:), getm(:,:), revm(:,:)
   integer(c_int), allocatable, target, save :: speer(:), sptr(:), slen(:), rpeer(:), rptr(:), rlen(:)
   real(c_double), allocatable, target, save :: dvv_c(:,:), hyai_c(:), hybi_c(:)
+  ! multi-rank halo exchange state (the bndry_exchangeV body, bndry_mod.F90:74-124, on staged host copies)
+  integer, save :: x_comm = -1, x_nsend = 0, x_nrecv = 0
+  integer(c_int), allocatable, target, save :: x_slen(:,:), x_rlen(:,:)     ! (slot, kind+1)
+  real(c_double), allocatable, target, save :: x_hsend(:), x_hrecv(:)
 
 contains
 
@@ -114,7 +129,7 @@ contains
     type(hvcoord_t),    intent(in) :: hvcoord
     type(tse_init_args) :: a
     integer :: ie, j, ns, nr, e2
-    if (hybrid%par%nprocs > 1) call abortmp('cuda_mod(hip): multi-rank halo callback not wired in this Fortran seam yet')
+    integer(c_int) :: ncs, ncr
     allocate(putm(8,nelemd), getm(8,nelemd), revm(8,nelemd))
     do ie = 1, nelemd
        putm(:,ie) = elem(ie)%desc%putmapP(1:8)
@@ -125,8 +140,20 @@ contains
     enddo
     allocate(dvv_c(np,np), hyai_c(nlevp), hybi_c(nlevp))
     dvv_c = deriv%Dvv; hyai_c = hvcoord%hyai; hybi_c = hvcoord%hybi
-    ns = 0; nr = 0
-    allocate(speer(1), sptr(1), slen(1), rpeer(1), rptr(1), rlen(1))
+    ! neighbour-rank slots exactly as genEdgeSched built them (schedule_mod.F90:36-239, schedtype_mod.F90:7-29)
+    ns = schedule(1)%nSendCycles; nr = schedule(1)%nRecvCycles
+    allocate(speer(max(ns,1)), sptr(max(ns,1)), slen(max(ns,1)), rpeer(max(nr,1)), rptr(max(nr,1)), rlen(max(nr,1)))
+    do j = 1, ns
+       speer(j) = schedule(1)%SendCycle(j)%dest - 1
+       sptr(j)  = schedule(1)%SendCycle(j)%ptrP
+       slen(j)  = schedule(1)%SendCycle(j)%lengthP
+    enddo
+    do j = 1, nr
+       rpeer(j) = schedule(1)%RecvCycle(j)%source - 1
+       rptr(j)  = schedule(1)%RecvCycle(j)%ptrP
+       rlen(j)  = schedule(1)%RecvCycle(j)%lengthP
+    enddo
+    x_comm = hybrid%par%comm; x_nsend = ns; x_nrecv = nr
     e2 = min(2, nelemd)
     a%nelemd = nelemd; a%qsize = qsize; a%device = -1; a%nu_q = nu_q
     a%limiter_option = limiter_option; a%rsplit = rsplit
@@ -140,8 +167,52 @@ contains
     a%nsend = ns; a%send_peer = c_loc(speer); a%send_ptrP = c_loc(sptr); a%send_lengthP = c_loc(slen)
     a%nrecv = nr; a%recv_peer = c_loc(rpeer); a%recv_ptrP = c_loc(rptr); a%recv_lengthP = c_loc(rlen)
     a%exchange = c_null_funptr; a%exchange_user = c_null_ptr
+    if (ns + nr > 0) a%exchange = c_funloc(tse_f_exchange)
     call check(tse_init(ctx, a), 'cuda_mod_init')
+    if (ns + nr > 0) then
+       allocate(x_slen(max(ns,1),2), x_rlen(max(nr,1),2))
+       x_slen(1:ns,1) = slen(1:ns); x_rlen(1:nr,1) = rlen(1:nr)
+       call check(tse_halo_minmax_layout(ctx, c_loc(x_slen(1,2)), c_loc(x_rlen(1,2))), 'tse_halo_minmax_layout')
+       call check(tse_halo_layout(ctx, ncs, ncr), 'tse_halo_layout')
+       ! largest message: max(qsize*nlev + nlev, 2*qsize*nlev) layers per column
+       allocate(x_hsend(max(1,ncs)*max(qsize*nlev + nlev, 2*qsize*nlev)), x_hrecv(max(1,ncr)*max(qsize*nlev + nlev, 2*qsize*nlev)))
+    endif
   end subroutine cuda_mod_init
+
+  ! bndry_exchangeV (bndry_mod.F90:74-124) on the packed slots: MPICH here is not GPU-aware, so the slots are staged
+  ! through host buffers; with a GPU-aware MPI the two hipMemcpy calls disappear and the device pointers go to MPI.
+  integer(c_int) function tse_f_exchange(user, sendbuf, recvbuf, nlyr, kind) bind(C)
+    type(c_ptr),    value :: user, sendbuf, recvbuf
+    integer(c_int), value :: nlyr, kind
+    integer :: i, off, ierr, nreq, ntot_s, ntot_r
+    integer :: req(x_nsend + x_nrecv), stat(MPI_STATUS_SIZE, x_nsend + x_nrecv)
+    tse_f_exchange = 1
+    ntot_s = sum(x_slen(1:x_nsend, kind+1)); ntot_r = sum(x_rlen(1:x_nrecv, kind+1))
+    if (ntot_s > 0) then
+       if (hipMemcpy(c_loc(x_hsend), sendbuf, int(ntot_s,c_size_t)*nlyr*8_c_size_t, 2_c_int) /= 0) return
+    endif
+    nreq = 0; off = 0
+    do i = 1, x_nrecv
+       if (x_rlen(i,kind+1) > 0) then
+          nreq = nreq + 1
+          call MPI_Irecv(x_hrecv(off*nlyr + 1), x_rlen(i,kind+1)*nlyr, MPI_DOUBLE_PRECISION, rpeer(i), 10, x_comm, req(nreq), ierr)
+       endif
+       off = off + x_rlen(i,kind+1)
+    enddo
+    off = 0
+    do i = 1, x_nsend
+       if (x_slen(i,kind+1) > 0) then
+          nreq = nreq + 1
+          call MPI_Isend(x_hsend(off*nlyr + 1), x_slen(i,kind+1)*nlyr, MPI_DOUBLE_PRECISION, speer(i), 10, x_comm, req(nreq), ierr)
+       endif
+       off = off + x_slen(i,kind+1)
+    enddo
+    call MPI_Waitall(nreq, req, stat, ierr)
+    if (ntot_r > 0) then
+       if (hipMemcpy(recvbuf, c_loc(x_hrecv), int(ntot_r,c_size_t)*nlyr*8_c_size_t, 1_c_int) /= 0) return
+    endif
+    tse_f_exchange = 0
+  end function tse_f_exchange
 
   integer(c_size_t) function estride(elem)
     type(element_t), intent(in), target :: elem(:)
