@@ -27,6 +27,19 @@ KERNEL_BYTES_PER_DOF = {"advance": (16.0 + 16.0 + 24.0) / 3.0, "dss": (16.0 + 16
                         "lap": 16.0, "minmax": 8.0, "remap": 16.0}
 
 
+def measured_traffic(ne, qsize, n_gpus, group):
+    """HBM bytes per launch of the dominant kernel group from the committed PMC passes (profiles/), collected exactly as
+    MI355X_MICROARCH.md prescribes (separate --pmc runs, FETCH_SIZE doubled on gfx950); None when the workload differs"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_ne120_q35.json")))
+        c = t["config"]
+        if (c["ne"], c["qsize"], c["n_gpus"]) == (ne, qsize, n_gpus):
+            return t["group_mean_hbm_bytes_per_launch"].get(group)
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def cpu_baseline(qsize, seconds_hint=20.0):
     """the reference itself (oracle/_ref/ref_harness: unmodified reference modules, MPI ranks on the host cores) on a
     bounded sample of the same workload; falls back to the C restatement (oracle/, OpenMP) if the binary is absent."""
@@ -135,7 +148,7 @@ def main():
                                    "%d elements sharded over %d GPU(s)" % (a.ne, a.qsize, run.nu_q, run.tstep, nelem_total, a.gpus),
                        "ne": a.ne, "nlev": 72, "qsize": a.qsize, "elements_per_gpu": int(run.mine.size)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_ms": ms / max(n, 1), "launches": n,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(a.ne, a.qsize, a.gpus, dom), "avg_ms": ms / max(n, 1), "launches": n,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
                          "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (a.gpus * HBM_PEAK_GBS * 1e9)},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in ktimes.items()},
