@@ -148,14 +148,25 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
   size_t mi = (size_t)e * qsize * NLEV + kc;
   double qn[4], ls[4], minp, maxp;
   load4(Qn0 + so, qn);
-  if (RHS >= 2) load4(lap + so, ls);
+  if (RHS == 3) load4(lap + so, ls);
   minp = qmin[mi]; maxp = qmax[mi];
   for (int q = 0; q < qsize; q++) {
     // software prefetch of the next tracer's slab row + bounds (vmcnt is in-order: issue everything for q+1 first)
     double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0, maxx = 0;
+    double bih[4] = {0, 0, 0, 0};
+    if (RHS == 2) {
+      // stage 3 with the second Laplacian in-kernel: register-bound (2 waves/SIMD), so the Laplacian input is not
+      // prefetched and the biharmonic term is formed first (its 40 VGPRs of metric constants are dead before the
+      // divergence starts).  Deeper prefetch in the spare registers and forcing 3 waves/SIMD (35 spills) were both slower.
+      double s0[4];
+      load4(lap + so, s0);
+      laplace_lean_row(D, L, s0, bih);
+#pragma unroll
+      for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
+    }
     if (q + 1 < qsize) {
       load4(Qn0 + so + qstride, qnx);
-      if (RHS >= 2) load4(lap + so + qstride, lsx);
+      if (RHS == 3) load4(lap + so + qstride, lsx);
       minx = qmin[mi + NLEV]; maxx = qmax[mi + NLEV];
     }
     double gv1[4], gv2[4], x[4], dx[4], dy[4];
@@ -186,10 +197,8 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
       maxp = fmax(maxp, quad_max(fmax(fmax(q0, q1), fmax(q2, q3))));
     }
     if (RHS == 2) {
-      double l2[4];
-      laplace_lean_row(D, L, ls, l2);
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = x[i] + visc[i] * l2[i];
+      for (int i = 0; i < 4; i++) x[i] = x[i] + bih[i];
     }
     if (RHS == 3) {
 #pragma unroll
