@@ -66,8 +66,8 @@ int main(int argc, char** argv) {
   double fb = trc * 8.0;
   timeit("copy_stream (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_stream, dim3(256 * 8), dim3(256), 0, 0, trc / 2, (const double2*)Q, (double2*)T); });
   timeit("copy_slab (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_slab, dim3(nelem), dim3(SLAB_THREADS), 0, 0, qsize, Q, T); });
-  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(nelem), dim3(SLAB_THREADS), 0, 0, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
-  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(nelem), dim3(SLAB_THREADS), 0, 0, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
+  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
+  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
   // DSS variants: synthetic regular topology W:e-1 E:e+1 S:e-ne N:e+ne (mod nelem)
   {
     std::vector<int2> tab((size_t)nelem * 48, make_int2(-1, 0)), tab0 = tab;
@@ -105,8 +105,8 @@ int main(int argc, char** argv) {
       hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
       int npair = (nelem + 1) / 2, nqc = (qsize + 4) / 5;
       dim3 g2(8 * ((npair + 7) / 8) * nqc);
-      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(nelem), dim3(SLAB_THREADS), 0, st, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); };
-      auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder); };
+      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); };
+      auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder, (const double*)nullptr, (double*)nullptr, (double*)nullptr); };
       timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });
       timeit("adv<1> then dss (serial)", 4 * fb, [&] { adv(0); dss(0); });
       // concurrent: note they touch the same T (race is irrelevant for timing)
@@ -125,6 +125,6 @@ int main(int argc, char** argv) {
     timeit("k_dss<0> old gather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });
     timeit("k_dss<0> old nogather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });
   }
-  timeit("k_qminmax", fb, [&] { hipLaunchKernelGGL(k_qminmax, dim3(nelem), dim3(SLAB_THREADS), 0, 0, qsize, 0.0, Q, dp, divdp_proj, qmin, qmax); });
+  timeit("k_qminmax", fb, [&] { hipLaunchKernelGGL(k_qminmax, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, qsize, 0.0, Q, dp, divdp_proj, qmin, qmax); });
   return 0;
 }

@@ -404,7 +404,7 @@ int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
 
 int tse_compute_divdp(tse_ctx* c) {
   Scope s(c, "level");
-  hipLaunchKernelGGL(k_divdp, dim3(c->nelemd), dim3(SLAB_THREADS), 0, c->stream, c->D, c->geo(), c->vn0, c->divdp, c->divdp_proj);
+  hipLaunchKernelGGL(k_divdp, dim3(flat_blocks(c->nelemd)), dim3(FLAT_THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->vn0, c->divdp, c->divdp_proj);
   LAUNCH_CHECK();
   return 0;
 }
@@ -503,31 +503,31 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
   double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
   double* var = DSSopt == 1 ? c->eta : DSSopt == 2 ? c->omega_p : DSSopt == 3 ? c->divdp_proj : nullptr;
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
-  const dim3 grid(c->nelemd), blk(SLAB_THREADS);
+  const dim3 grid(flat_blocks(c->nelemd)), blk(FLAT_THREADS);
   if (rhs == 0) {
     if (fused_mm && c->mm_valid == n0_qdp) {
       // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
       std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
     } else {
       Scope s(c, "minmax");
-      hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
     }
     c->mm_valid = 0;
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
-    hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+    hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
                        c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
     LAUNCH_CHECK();
   } else if (rhs == 1) {
     Scope s(c, "advance");
-    hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+    hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
                        c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
     LAUNCH_CHECK();
   } else {
     if (!fused) {   // in the fused whole-step path the stage-2 DSS (k_dss_t<3>) has already produced B, qmin, qmax
       Scope s(c, "lap");
-      hipLaunchKernelGGL(k_lap1, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      hipLaunchKernelGGL(k_lap1, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
     }
     // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1)
@@ -560,10 +560,10 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
     if (fused)
-      hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+      hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
                          c->divdp_proj, c->qmin, c->qmax, c->dp0);
     else
-      hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+      hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
                          c->divdp_proj, c->qmin, c->qmax, c->dp0);
     LAUNCH_CHECK();
   }

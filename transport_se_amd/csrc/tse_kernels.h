@@ -13,7 +13,21 @@
 
 namespace tse {
 
-constexpr int SLAB_THREADS = 320;  // 72 levels x 4 rows = 288 active lanes (4.5 waves)
+constexpr int SLAB_THREADS = 320;  // k_dss_t: block = element, 72 levels x 4 rows = 288 active lanes (4.5 waves)
+// The slab kernels (k_divdp, k_qminmax, k_advance, k_lap1) run over the flattened slab index s = e*NLEV + k instead: a
+// 72-level element is 4.5 waves, so element-sized blocks idle 10% of their lanes and -- worse -- come in units of 5 waves,
+// which leaves SIMD wave slots empty whenever the register budget allows 2 or 3 waves per SIMD (8 or 12 per CU).
+constexpr int FLAT_THREADS = 256;
+struct SlabId { int e, k; bool live; };
+__device__ __forceinline__ SlabId flat_slab(int nelemd) {
+  const int n = nelemd * NLEV, gs = blockIdx.x * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
+  SlabId s;
+  s.live = gs < n;
+  const int g = s.live ? gs : n - 1;   // idle tail lanes recompute the last slab and store nothing
+  s.e = g / NLEV; s.k = g - s.e * NLEV;
+  return s;
+}
+inline int flat_blocks(int nelemd) { return (nelemd * NLEV * 4 + FLAT_THREADS - 1) / FLAT_THREADS; }
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
@@ -21,9 +35,10 @@ struct GeoPtrs {
 
 // ---------------------------------------------------------------------------------------------------
 // divdp = divdp_proj = divergence_sphere(vn0)   (prim_advection_mod.F90:614-623)
-__global__ __launch_bounds__(SLAB_THREADS) void k_divdp(Dvv_t D, GeoPtrs G, const double* __restrict__ vn0,
+__global__ __launch_bounds__(FLAT_THREADS) void k_divdp(int nelemd, Dvv_t D, GeoPtrs G, const double* __restrict__ vn0,
                                                         double* __restrict__ divdp, double* __restrict__ divdp_proj) {
-  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  const SlabId sid = flat_slab(nelemd);
+  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   RowGeo g;
   load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
   double v1[4], v2[4], div[4];
@@ -38,11 +53,12 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_divdp(Dvv_t D, GeoPtrs G, cons
 
 // ---------------------------------------------------------------------------------------------------
 // element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
-__global__ __launch_bounds__(SLAB_THREADS) void k_qminmax(int qsize, double rdt /* rhs_multiplier*dt */,
+__global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize, double rdt /* rhs_multiplier*dt */,
                                                           const double* __restrict__ Qn0, const double* __restrict__ dp,
                                                           const double* __restrict__ divdp_proj,
                                                           double* __restrict__ qmin, double* __restrict__ qmax) {
-  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  const SlabId sid = flat_slab(nelemd);
+  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   double dpk[4], dv[4];
   const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
   load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
@@ -101,13 +117,14 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 template <int RHS>
-__global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
+__global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0) {
-  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  const SlabId sid = flat_slab(nelemd);
+  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
   //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
@@ -227,11 +244,12 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_advance(Dvv_t D, GeoPtrs G, in
 // ---------------------------------------------------------------------------------------------------
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
-__global__ __launch_bounds__(SLAB_THREADS) void k_lap1(Dvv_t D, GeoPtrs G, int qsize, double rdt,
+__global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax) {
-  const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  const SlabId sid = flat_slab(nelemd);
+  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   LapGeo L;
   {
     RowGeo g;
