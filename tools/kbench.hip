@@ -103,8 +103,8 @@ int main(int argc, char** argv) {
     }
     {   // overlap experiment: VALU-bound advance and memory-bound DSS on two streams, each on half of the tracers' worth of elements
       hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
-      int npair = (nelem + 1) / 2, nqc = (qsize + 4) / 5;
-      dim3 g2(8 * ((npair + 7) / 8) * nqc);
+      int nqc = (qsize + 4) / 5;
+      dim3 g2(8 * dss2_blocks_per_xcd(nelem) * nqc);
       auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); };
       auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder, (const double*)nullptr, (double*)nullptr, (double*)nullptr); };
       timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });

@@ -464,8 +464,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     Scope s(c, "dss");
     const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
     const dim3 grid(8 * ((c->nelemd + 7) / 8) * nqc);
-    const int npair = (c->nelemd + 1) / 2;
-    const dim3 grid2(8 * ((npair + 7) / 8) * nqc);
+    const dim3 grid2(8 * dss2_blocks_per_xcd(c->nelemd) * nqc);
     // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: (qsize*72 + 72) always is
     if (Qn0_avg)
       hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
@@ -550,8 +549,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
         hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
                            (const double*)nullptr, c->recvbuf, nq, X, c->order);
       } else {
-        const int npair = (c->nelemd + 1) / 2;
-        hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * ((npair + 7) / 8) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
+        hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * dss2_blocks_per_xcd(c->nelemd) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
                            c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order, (const double*)nullptr, (double*)nullptr,
                            (double*)nullptr);
       }

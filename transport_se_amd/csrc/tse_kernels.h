@@ -465,8 +465,10 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
 // Default tracer DSS: as k_dss_t<0|1>, but every lane handles TWO consecutive levels, so that each own/neighbour access is
 // a 16-byte load (the level-fastest source makes the level pair contiguous).  The 8-byte version spent as much time
 // issuing the 12 loads per tracer as moving the data (a variant whose gathers all hit the lane's own element in L1 was
-// as slow as the real one).  Block = 2 elements x 36 level pairs x 4 rows = 288 threads.
-constexpr int DSS2_THREADS = 320;
+// as slow as the real one).
+constexpr int DSS2_THREADS = 256;
+constexpr int DSS2_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs x 4 rows
+inline int dss2_blocks_per_xcd(int nelemd) { return (((nelemd + 7) >> 3) * DSS2_UNITS + DSS2_THREADS - 1) / DSS2_THREADS; }
 template <int MODE>
 __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
                                                          const double* __restrict__ rspheremp, const double* __restrict__ src,
@@ -476,14 +478,16 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
                                                          double* __restrict__ mn_out, double* __restrict__ mx_out) {
   // mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
   // next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
-  const int npair = (nelemd + 1) >> 1;               // element pairs
-  const int S8 = (npair + 7) >> 3;
+  // Work = (tracer chunk, XCD range of elements, flattened (element slot, level pair, row)): 144 lanes per element do not
+  // fill whole waves, so the lanes of a block run across element boundaries (no idle lanes except in a range's last block).
+  const int S8 = (nelemd + 7) >> 3;                                         // elements per XCD range (as in `order`)
+  const int B8 = (S8 * DSS2_UNITS + DSS2_THREADS - 1) / DSS2_THREADS;       // blocks per XCD range and tracer chunk
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
-  const int pslot = xcd * S8 + it % S8, qc = it / S8;
-  const int tid = threadIdx.x;
-  const int el = tid / 144, r = tid % 144;
-  const int slot = pslot * 2 + el;
-  if (pslot >= npair || slot >= nelemd || tid >= 288) return;
+  const int bi = it % B8, qc = it / B8;
+  const int g = bi * DSS2_THREADS + threadIdx.x;
+  const int idx = g / DSS2_UNITS, r = g - idx * DSS2_UNITS;
+  const int slot = xcd * S8 + idx;
+  if (idx >= S8 || slot >= nelemd) return;
   const int e = order[slot];
   const int k0 = (r >> 2) * 2, j = r & 3;            // levels k0, k0+1
   constexpr int NS = 8;
