@@ -18,16 +18,20 @@ constexpr int SLAB_THREADS = 320;  // k_dss_t: block = element, 72 levels x 4 ro
 // 72-level element is 4.5 waves, so element-sized blocks idle 10% of their lanes and -- worse -- come in units of 5 waves,
 // which leaves SIMD wave slots empty whenever the register budget allows 2 or 3 waves per SIMD (8 or 12 per CU).
 constexpr int FLAT_THREADS = 256;
+// Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
+// XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[e][q][p][:]
+// rows through the same L2 (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
 struct SlabId { int e, k; bool live; };
 __device__ __forceinline__ SlabId flat_slab(int nelemd) {
-  const int n = nelemd * NLEV, gs = blockIdx.x * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
+  const int per = gridDim.x >> 3, lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   SlabId s;
   s.live = gs < n;
   const int g = s.live ? gs : n - 1;   // idle tail lanes recompute the last slab and store nothing
   s.e = g / NLEV; s.k = g - s.e * NLEV;
   return s;
 }
-inline int flat_blocks(int nelemd) { return (nelemd * NLEV * 4 + FLAT_THREADS - 1) / FLAT_THREADS; }
+inline int flat_blocks(int nelemd) { return 8 * ((nelemd * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
