@@ -145,6 +145,33 @@ def test_negative_layer_thickness_is_reported(ctx5):
         hip.vertical_remap(1.0e9, 2)
 
 
+@pytest.mark.parametrize("nt,generic,squeeze", [(1, 0, False), (2, 0, False), (2, 1, False), (1, 0, True), (2, 0, True)])
+def test_remap_column_loop_variants(ctx5, monkeypatch, nt, generic, squeeze):
+    """k_remap's lockstep column loop (kid(k) in {k,k+1}; 1 or 2 tracers per thread) and its generic loop against the
+    oracle's remap_Q_ppm.  squeeze: a Lagrangian grid compressed to 0.3x in the upper half and stretched to 1.7x below,
+    i.e. interfaces displaced by up to ~25 layers, which the kernel must detect and route through the generic loop."""
+    o, elem, hip = ctx5
+    monkeypatch.setenv("TSE_REMAP_NT", str(nt)); monkeypatch.setenv("TSE_REMAP_GENERIC", str(generic))
+    o.dcmip_init(1); o.dcmip_step_inputs(1, 0, 1800.0)
+    _upload_state(o, elem, hip)
+    o.advec_tracers_remap_rk2(600.0, 0)
+    hip.advec_tracers_remap_rk2(600.0, 1, 2)
+    dt = 600.0
+    if squeeze:
+        f = np.where(np.arange(72) < 36, 0.3, 1.7)
+        o.divdp_proj[...] = o.dp * (1.0 - f)[None, :, None, None] / dt
+        elem["divdp"][...] = o.divdp; elem["divdp_proj"][...] = o.divdp_proj
+        hip.set_divdp(elem)
+    o.vertical_remap(dt, 2)
+    hip.vertical_remap(dt, 2)
+    hip.copy_qdp_d2h(elem, 2); hip.get_derived(elem)
+    assert relerr(elem["dp3d"], o.dp3d) < 1e-15 and relerr(elem["ps_v"], o.ps_v) < 1e-15
+    for q in range(5):
+        assert relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q]) < 4 * TOL_STEP, q
+    mass_h = np.einsum("eji,eqkji->q", o.spheremp, elem["Qdp"][:, 1, :5]); mass_o = np.einsum("eji,eqkji->q", o.spheremp, o.qdp[1])
+    assert np.all(np.abs(mass_h - mass_o) <= 1e-13 * np.abs(mass_o))
+
+
 def test_limiter_edge_cases_through_the_step(ctx5):
     """infeasible bounds (SSP CFL>1 style), uniform fields and a 0/1 checkerboard through k_advance's limiter:
     compare with the oracle's limiter_optim_iter_full on identical inputs"""

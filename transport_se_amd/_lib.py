@@ -31,7 +31,9 @@ def build(force=False, verbose=False):
     newest = max(os.path.getmtime(p) for p in SRC + [HDR])
     if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-shared", "-fPIC", "-o", SO, SRC[0]]
+    # -fno-honor-nans: value-preserving (no reassociation, no reciprocal tricks); it only lets the compiler drop the
+    # v_max_f64 x,x "canonicalize" it otherwise puts in front of every fmin/fmax operand (6 per limiter iteration)
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-honor-nans", "-shared", "-fPIC", "-o", SO, SRC[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -56,7 +58,7 @@ def lib():
     if not os.path.exists(SO):
         raise RuntimeError("libtransport_se_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the product path)")
-    L = C.CDLL(SO)
+    L = C.CDLL(os.environ.get("TSE_LIB", SO))   # TSE_LIB: A/B builds of the same sources (tools/), never a fallback
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     L.tse_init.argtypes = [C.POINTER(vp), C.POINTER(InitArgs)]
     L.tse_finalize.argtypes = [vp]; L.tse_finalize.restype = None

@@ -298,7 +298,8 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
     if (dalloc(&c->sendbuf, (size_t)std::max(1, c->ncol_send) * c->nlyr_halo) || dalloc(&c->recvbuf, (size_t)std::max(1, c->ncol_recv) * c->nlyr_halo)) return 1;
     c->own_halo = true;
   }
-  HIPCHK(hipFuncSetAttribute((const void*)k_remap, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipDeviceSynchronize());
   *out = c;
   return 0;
@@ -601,8 +602,16 @@ int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
   if (np1_qdp < 1 || np1_qdp > 2) return fail("vertical_remap: np1_qdp=%d", np1_qdp);
   {
     Scope s(c, "remap");
-    hipLaunchKernelGGL(k_remap, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp + (size_t)(np1_qdp - 1) * c->trc(), c->bad, c->qmin2, c->qmax2);
+    // TSE_REMAP_NT: tracers per thread in the lockstep column loop; TSE_REMAP_GENERIC=1: always take the generic loop (tests)
+    const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
+    const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
+    double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+    if (nt == 1)
+      hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic);
+    else
+      hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic);
     LAUNCH_CHECK();
   }
   int bad = 0;

@@ -212,20 +212,24 @@ __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], do
     if (done && my_it == 16) my_it = iter;
 #endif
     if (__all(done)) break;  // wave-uniform exit; slabs already converged are left untouched below
-    // redistribute over the points that are not pinned at the bound the mass moves towards (:1052-1078)
-    const bool up = addmass > 0.0;
-    const double bound = up ? maxp : minp;
-    double w = 0.0;
-    bool fr[4];
+    // redistribute over the points that are not pinned at the bound the mass moves towards (:1052-1078).  After the clip
+    // x is inside [minp,maxp], so "x < maxp" (mass moving up) / "x > minp" (down) is just x != bound.  The selection is
+    // carried as an exact 0.0/1.0 factor (one v_cndmask on the high word) folded into FMAs: fma(1,c,w) = w+c and
+    // fma(1,inc,x) = x+inc round exactly like the reference's additions, fma(0,.,x) = x -- instead of 64-bit selects
+    // (two v_cndmask each) around every add.
+    const double bound = addmass > 0.0 ? maxp : minp;
+    double m[4], w = 0.0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      fr[i] = up ? (x[i] < bound) : (x[i] > bound);
-      w = w + (fr[i] ? c[i] : 0.0);
+      m[i] = __hiloint2double(x[i] != bound ? 0x3ff00000 : 0, 0);
+      w = fma(m[i], c[i], w);
     }
     w = quad_sum(w);
-    const double inc = done ? 0.0 : addmass / w;
+    // w == 0: every point is pinned (e.g. minp == maxp); the reference then applies addmass/weightssum to nobody, and an
+    // infinite increment must not reach the 0-factor FMAs
+    const double inc = (done || w <= 0.0) ? 0.0 : addmass / w;
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = fr[i] ? x[i] + inc : x[i];
+    for (int i = 0; i < 4; i++) x[i] = fma(m[i], inc, x[i]);
   }
 #ifdef TSE_LIMITER_STATS
   if ((threadIdx.x & 3) == 0) atomicAdd(&g_lim_hist[my_it], 1ull);

@@ -612,6 +612,7 @@ struct RemapLds {
   double z2[NLEV][16];
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
+  int slow;                        // some column has kid(k) outside {k, k+1}
 };
 __device__ __forceinline__ double ppm_dma(double d0, double d1, double d2, double am, double a0, double ap) {
   double da = d0 * (d1 * (ap - a0) + d2 * (a0 - am));
@@ -637,75 +638,14 @@ __device__ __forceinline__ void remap_coefs(double al, double ar, double a0, dou
   c1 = ar - al;
   c2 = -6. * a0 + 3. * (al + ar);
 }
-__global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
-                                                         const double* __restrict__ hybi, const double* __restrict__ dp,
-                                                         const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
-                                                         double* __restrict__ ps_v, double* __restrict__ Q,
-                                                         int* __restrict__ bad, double* __restrict__ mn_out,
-                                                         double* __restrict__ mx_out) {
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
-  const int e = blockIdx.x, tid = threadIdx.x;
-  // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
-  for (int w = tid; w < NLEV * 16; w += REMAP_THREADS) {
-    size_t o = (size_t)e * NLEV * 16 + w;
-    double d = dp[o] - dt * divdp_proj[o];
-    dp3d[o] = d;
-    S.dpo[(w >> 4) + 2][w & 15] = d;
-    S.dpn[w >> 4][w & 15] = dp[o];
-    if (d < 0) atomicOr(bad, 1);
-  }
-  __syncthreads();
-  if (tid < 16) {
-    const int p = tid;
-    double s = 0.0;
-    for (int k = 0; k < NLEV; k++) s += S.dpo[k + 2][p];
-    double ps = hyai[0] * ps0 + s;
-    ps_v[(size_t)e * 16 + p] = ps;
-    double pio_prev = 0.0;
-    S.pio[0][p] = 0.0;
-    for (int k = 1; k <= NLEV; k++) { pio_prev = pio_prev + S.dpo[k + 1][p]; S.pio[k][p] = pio_prev; }
-    S.pio[NLEV + 1][p] = pio_prev + 1.;
-    for (int k = 1; k <= 2; k++) { S.dpo[2 - k][p] = S.dpo[k + 1][p]; S.dpo[NLEV + k + 1][p] = S.dpo[NLEV + 2 - k][p]; }
-    double pin = 0.0;
-    int kk = 1;
-    for (int k = 1; k <= NLEV; k++) {
-      double dpn = (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
-      pin = pin + dpn;
-      double pin_k1 = (k == NLEV) ? S.pio[NLEV][p] : pin;  // pin(nlev+1) = pio(nlev+1)
-      kk = k;
-      while (S.pio[kk - 1][p] <= pin_k1) kk++;
-      kk--;
-      if (kk == NLEV + 1) kk = NLEV;
-      S.kid[k - 1][p] = kk;
-      S.z2[k - 1][p] = (pin_k1 - (S.pio[kk - 1][p] + S.pio[kk][p]) * 0.5) / S.dpo[kk + 1][p];
-    }
-  }
-  __syncthreads();
-  // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260), one (j,p) per work item
-  for (int w = tid; w < (NLEV + 4) * 16; w += REMAP_THREADS) S.rdpo[w >> 4][w & 15] = 1.0 / S.dpo[w >> 4][w & 15];
-  for (int w = tid; w < (NLEV + 2) * 16; w += REMAP_THREADS) {
-    const int jj = w >> 4, p = w & 15;  // jj = j, j = 0..NLEV+1
-#define DX(j) S.dpo[(j) + 1][p]
-    S.ppmdx[jj][0][p] = DX(jj) / (DX(jj - 1) + DX(jj) + DX(jj + 1));
-    S.ppmdx[jj][1][p] = (2. * DX(jj - 1) + DX(jj)) / (DX(jj + 1) + DX(jj));
-    S.ppmdx[jj][2][p] = (DX(jj) + 2. * DX(jj + 1)) / (DX(jj - 1) + DX(jj));
-    if (jj <= NLEV) {
-      S.ppmdx[jj][3][p] = DX(jj) / (DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][4][p] = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
-      S.ppmdx[jj][5][p] = (2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][6][p] = (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][7][p] = (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj));
-      S.ppmdx[jj][8][p] = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][9][p] = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
-    }
-#undef DX
-  }
-  __syncthreads();
-  // ---- phase 2: data part (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209)
-  // Plain straight-line code on purpose: lambdas/arrays passed by pointer ended up in scratch memory inside this loop.
+// Generic column loop (any kid(k) >= k-1): thread = (tracer, column) walks down the column, advancing a 5-cell window by a
+// data-dependent number of cells per level (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209).
+// Only taken by elements whose Lagrangian interfaces moved by more than one layer somewhere (see k_remap).
+// Plain straight-line code on purpose: lambdas/arrays passed by pointer ended up in scratch memory inside this loop.
+__device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
+                                                   double* __restrict__ mn_out, double* __restrict__ mx_out) {
   const int p = tid & 15;
-  for (int q = tid >> 4; q < qsize; q += REMAP_THREADS / 16) {
+  for (int q = tid >> 4; q < qsize; q += nthreads >> 4) {
     double* col = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
     // Cells are consumed strictly in order 1,2,3,...; a register FIFO keeps REMAP_PF column loads in flight per thread.
     int R = 0;                                   // highest cell consumed so far (ghost cells continue past NLEV)
@@ -763,6 +703,186 @@ __global__ __launch_bounds__(REMAP_THREADS) void k_remap(int qsize, double dt, d
     }
 #undef TSE_READ_NEXT
   }
+}
+
+// Lockstep column loop for the normal case kid(k) in {k, k+1} for every level of every column of the element (the
+// interfaces moved by less than one layer: vertical CFL < 1).  All lanes then consume exactly one old cell per level, so
+// the loop is branch-free and statically scheduled: at level k every lane reads cell k+3, forms dma(k+2) and ai(k+1)
+// (compute_ppm stages 1-2), and picks the parabola of cell k or k+1 by its own offset o = kid(k)-k.  Loads sit in a
+// register FIFO with compile-time slots (the level loop is unrolled by REMAP_PF), NT tracers per thread share every LDS
+// read and the level-only part of integrate_parabola.  Arithmetic per value is the same, in the same order, as in the
+// generic loop.
+template <int NT>
+__device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
+                                                   double* __restrict__ mn_out, double* __restrict__ mx_out) {
+  const int p = tid & 15;
+  for (int q0 = (tid >> 4) * NT; q0 < qsize; q0 += (nthreads >> 4) * NT) {
+    double* col[NT];
+    bool on[NT];
+    int qq[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      on[t] = q0 + t < qsize;
+      qq[t] = on[t] ? q0 + t : qsize - 1;   // a surplus slot recomputes the last tracer and stores nothing
+      col[t] = Q + ((size_t)e * qsize + qq[t]) * NLEV * 16 + p;
+    }
+    double pf[NT][REMAP_PF];
+    double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      mk[t] = col[t][0]; mk1[t] = col[t][16]; mk2[t] = col[t][32];
+#pragma unroll
+      for (int r = 0; r < REMAP_PF; r++) pf[t][r] = col[t][(size_t)(r + 3) * 16];   // cells 4 .. 3+REMAP_PF
+    }
+    {
+      const double r1 = S.rdpo[2][p], r2 = S.rdpo[3][p], r3 = S.rdpo[4][p];
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        ak[t] = mk[t] * r1; ak1[t] = mk1[t] * r2; ak2[t] = mk2[t] * r3;
+        // a(0) = a(1), a(-1) = a(2)
+        const double dma0 = remap_dma_at(S, 0, p, ak1[t], ak[t], ak[t]);
+        const double dma1 = remap_dma_at(S, 1, p, ak[t], ak[t], ak1[t]);
+        dmak1[t] = remap_dma_at(S, 2, p, ak[t], ak1[t], ak2[t]);
+        aikm1[t] = remap_ai_at(S, 0, p, ak[t], ak[t], dma1, dma0);
+        aik[t] = remap_ai_at(S, 1, p, ak[t], ak1[t], dmak1[t], dma1);
+        masso[t] = 0.0; massn1[t] = 0.0;
+      }
+    }
+    for (int kb = 0; kb < NLEV; kb += REMAP_PF) {
+#pragma unroll
+      for (int sl = 0; sl < REMAP_PF; sl++) {
+        const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
+        double ak3[NT], mk3[NT];
+        if (r <= NLEV) {
+          const double rr = S.rdpo[r + 1][p];
+#pragma unroll
+          for (int t = 0; t < NT; t++) {
+            mk3[t] = pf[t][sl];
+            if (r + REMAP_PF <= NLEV) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
+            ak3[t] = mk3[t] * rr;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; t++) {   // a(nlev+1) = a(nlev), a(nlev+2) = a(nlev-1); nothing beyond is used
+            mk3[t] = 0.0;
+            ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
+          }
+        }
+        const int jd = k + 2 <= NLEV + 1 ? k + 2 : NLEV + 1, ja = k + 1 <= NLEV ? k + 1 : NLEV;   // last level: results unused
+        const double d0 = S.ppmdx[jd][0][p], d1 = S.ppmdx[jd][1][p], d2 = S.ppmdx[jd][2][p];
+        const double e3 = S.ppmdx[ja][3][p], e4 = S.ppmdx[ja][4][p], e5 = S.ppmdx[ja][5][p], e6 = S.ppmdx[ja][6][p],
+                     e7 = S.ppmdx[ja][7][p], e8 = S.ppmdx[ja][8][p], e9 = S.ppmdx[ja][9][p];
+        const int kt = S.kid[k - 1][p];
+        const bool o = kt != k;   // kid(k) == k+1
+        const double x1 = -0.5, x2 = S.z2[k - 1][p], dsel = S.dpo[kt + 1][p], dn = S.dpn[k - 1][p];
+        const double z1 = x2 - x1, zz2 = (x2 * x2 - x1 * x1) * 0.5, z3 = x2 * x2 * x2 - x1 * x1 * x1;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
+          const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e5 * (e6 - e7) * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
+          const double mo1 = masso[t] + mk[t];
+          const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
+          double c0, c1, c2;
+          remap_coefs(al, ar, a0, c0, c1, c2);
+          const double integ = c0 * z1 + c1 * zz2 + c2 * z3 * (1.0 / 3.0);
+          const double massn2 = ms + integ * dsel;
+          const double qnew = massn2 - massn1[t];
+          if (on[t]) col[t][(size_t)(k - 1) * 16] = qnew;
+          massn1[t] = massn2;
+          if (mn_out) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
+            const double x = qnew / dn;
+            double mn = x, mx = x;
+            mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
+            mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
+            if (p == 0 && on[t]) { mn_out[((size_t)e * qsize + qq[t]) * NLEV + k - 1] = mn; mx_out[((size_t)e * qsize + qq[t]) * NLEV + k - 1] = mx; }
+          }
+          masso[t] = mo1;
+          ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
+          mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
+          dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
+                                                         const double* __restrict__ hybi, const double* __restrict__ dp,
+                                                         const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
+                                                         double* __restrict__ ps_v, double* __restrict__ Q,
+                                                         int* __restrict__ bad, double* __restrict__ mn_out,
+                                                         double* __restrict__ mx_out, int force_generic) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
+  const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+  if (tid == 0) S.slow = force_generic;
+  // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
+  for (int w = tid; w < NLEV * 16; w += nthreads) {
+    size_t o = (size_t)e * NLEV * 16 + w;
+    double d = dp[o] - dt * divdp_proj[o];
+    dp3d[o] = d;
+    S.dpo[(w >> 4) + 2][w & 15] = d;
+    S.dpn[w >> 4][w & 15] = dp[o];
+    if (d < 0) atomicOr(bad, 1);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int p = tid;
+    double s = 0.0;
+    for (int k = 0; k < NLEV; k++) s += S.dpo[k + 2][p];
+    double ps = hyai[0] * ps0 + s;
+    ps_v[(size_t)e * 16 + p] = ps;
+    double pio_prev = 0.0;
+    S.pio[0][p] = 0.0;
+    for (int k = 1; k <= NLEV; k++) { pio_prev = pio_prev + S.dpo[k + 1][p]; S.pio[k][p] = pio_prev; }
+    S.pio[NLEV + 1][p] = pio_prev + 1.;
+    for (int k = 1; k <= 2; k++) { S.dpo[2 - k][p] = S.dpo[k + 1][p]; S.dpo[NLEV + k + 1][p] = S.dpo[NLEV + 2 - k][p]; }
+    // new-grid interface pressures pin(k+1) (serial sum, as the reference's :150-158), parked in z2's slot until the
+    // bracket search below replaces them
+    double pin = 0.0;
+    for (int k = 1; k <= NLEV; k++) {
+      double dpn = (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
+      pin = pin + dpn;
+      S.z2[k - 1][p] = (k == NLEV) ? pio_prev : pin;  // pin(nlev+1) = pio(nlev+1)
+    }
+  }
+  __syncthreads();
+  // bracket search (:160-172), one (k,p) per work item: every level starts its own search at kk = k
+  for (int w = tid; w < NLEV * 16; w += nthreads) {
+    const int k = (w >> 4) + 1, p = w & 15;
+    const double pin_k1 = S.z2[k - 1][p];
+    int kk = k;
+    while (S.pio[kk - 1][p] <= pin_k1) kk++;
+    kk--;
+    if (kk == NLEV + 1) kk = NLEV;
+    S.kid[k - 1][p] = kk;
+    if (kk != k && kk != k + 1) S.slow = 1;   // a displacement of more than one layer: this element takes the generic loop
+    S.z2[k - 1][p] = (pin_k1 - (S.pio[kk - 1][p] + S.pio[kk][p]) * 0.5) / S.dpo[kk + 1][p];
+  }
+  // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260), one (j,p) per work item
+  for (int w = tid; w < (NLEV + 4) * 16; w += nthreads) S.rdpo[w >> 4][w & 15] = 1.0 / S.dpo[w >> 4][w & 15];
+  for (int w = tid; w < (NLEV + 2) * 16; w += nthreads) {
+    const int jj = w >> 4, p = w & 15;  // jj = j, j = 0..NLEV+1
+#define DX(j) S.dpo[(j) + 1][p]
+    S.ppmdx[jj][0][p] = DX(jj) / (DX(jj - 1) + DX(jj) + DX(jj + 1));
+    S.ppmdx[jj][1][p] = (2. * DX(jj - 1) + DX(jj)) / (DX(jj + 1) + DX(jj));
+    S.ppmdx[jj][2][p] = (DX(jj) + 2. * DX(jj + 1)) / (DX(jj - 1) + DX(jj));
+    if (jj <= NLEV) {
+      S.ppmdx[jj][3][p] = DX(jj) / (DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][4][p] = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
+      S.ppmdx[jj][5][p] = (2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][6][p] = (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][7][p] = (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj));
+      S.ppmdx[jj][8][p] = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
+      S.ppmdx[jj][9][p] = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
+    }
+#undef DX
+  }
+  __syncthreads();
+  // ---- phase 2: data part
+  if (S.slow) remap_columns_generic(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
+  else remap_columns_fast<NT>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
 }
 
 // ---------------------------------------------------------------------------------------------------

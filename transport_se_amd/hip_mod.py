@@ -116,6 +116,14 @@ class HipMod:
         v, sv = arg("vn0"); d, sd = arg("dp"); e, se = arg("eta_dot_dpdn"); o, so = arg("omega_p")
         self._chk(self.L.tse_set_derived(self.h, v, sv, d, sd, e, se, o, so))
 
+    def set_divdp(self, elem):
+        """derived%divdp / divdp_proj as the host computed them (prim_advection_mod.F90:614-623)"""
+        args = []
+        for name in ("divdp", "divdp_proj"):
+            x = elem.get(name)
+            args += [_vp(x), x.strides[0]] if x is not None else [None, 0]
+        self._chk(self.L.tse_set_divdp(self.h, *args))
+
     def get_derived(self, elem):
         args = []
         for name in ("divdp_proj", "eta_dot_dpdn", "omega_p", "divdp", "dp3d", "ps_v"):
