@@ -66,8 +66,8 @@ int main(int argc, char** argv) {
   double fb = trc * 8.0;
   timeit("copy_stream (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_stream, dim3(256 * 8), dim3(256), 0, 0, trc / 2, (const double2*)Q, (double2*)T); });
   timeit("copy_slab (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_slab, dim3(nelem), dim3(SLAB_THREADS), 0, 0, qsize, Q, T); });
-  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
-  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); });
+  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); });
+  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); });
   // DSS variants: synthetic regular topology W:e-1 E:e+1 S:e-ne N:e+ne (mod nelem)
   {
     std::vector<int2> tab((size_t)nelem * 48, make_int2(-1, 0)), tab0 = tab;
@@ -92,20 +92,20 @@ int main(int argc, char** argv) {
     int* dorder; CK(hipMalloc(&dorder, nelem * 4)); CK(hipMemcpy(dorder, ho.data(), nelem * 4, hipMemcpyHostToDevice));
     for (int qb : {1, 5, 35}) {
       int nqc = (qsize + qb - 1) / qb;
-      dim3 grid(8 * ((nelem + 7) / 8) * nqc);
+      dim3 grid(8 * dss_blocks_per_xcd<NLEV * 4>(nelem) * nqc);
       char nm[64];
       snprintf(nm, 64, "k_dss_t<0> qb=%d nogather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
       snprintf(nm, 64, "k_dss_t<0> qb=%d selfgather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtabs, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtabs, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
       snprintf(nm, 64, "k_dss_t<0> qb=%d gather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(SLAB_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
+      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
     }
     {   // overlap experiment: VALU-bound advance and memory-bound DSS on two streams, each on half of the tracers' worth of elements
       hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
       int nqc = (qsize + 4) / 5;
       dim3 g2(8 * dss2_blocks_per_xcd(nelem) * nqc);
-      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0); };
+      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); };
       auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder, (const double*)nullptr, (double*)nullptr, (double*)nullptr); };
       timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });
       timeit("adv<1> then dss (serial)", 4 * fb, [&] { adv(0); dss(0); });

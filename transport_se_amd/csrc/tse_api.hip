@@ -22,6 +22,8 @@ using namespace tse;
 static const int DSS_QB = 5;  // tracers per k_dss_t block
 // TSE_FUSE_STAGE3=1 selects the variant that folds the first Laplacian into the stage-2 DSS and the second Laplacian
 // into the Laplacian's DSS (two field passes fewer, but 170-190 VGPRs -> 5 waves/CU: slower at present)
+// TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
+static bool dss_on_read() { const char* e = getenv("TSE_DSS_ON_READ"); return !(e && e[0] == '0'); }
 static bool fuse_stage3() { static int v = -1; if (v < 0) { const char* e = getenv("TSE_FUSE_STAGE3"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
 
 static thread_local char g_err[512] = "";
@@ -69,6 +71,8 @@ struct tse_ctx {
   std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
   std::vector<hipEvent_t> free_events;
   double *lvl_tmp2 = nullptr;
+  bool t_zero_dirty = false;   // the per-stage stage-3 path used T as a plain [e][q][k][p] field (overwrites its zero elements)
+  size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
   GeoPtrs geo() const { return GeoPtrs{Dinv, metdet, rmetdet, spheremp, rspheremp}; }
@@ -279,13 +283,18 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
 
   // ---- state -------------------------------------------------------------------------------------
   const size_t lev = c->lev(), trc = c->trc();
-  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, trc) || dalloc(&c->B, trc)) return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
+  // scratch fields T, B: one plane per tracer = local elements + one all-zero element (target of empty gather slots) +
+  // the received halo columns (DSS-on-read reads them from there); see tse_kernels.h
+  c->tps = (((size_t)(n + 1) * 16 * NLEV + (size_t)std::max(0, c->ncol_recv) * NLEV) + 15) / 16 * 16;
+  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps))
+    return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
+  HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
       dalloc(&c->lvl_tmp, lev) || dalloc(&c->lvl_tmp2, lev)) return 1;
   const size_t mm = (size_t)n * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
-  HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8)); HIPCHK(hipMemset(c->T, 0, trc * 8)); HIPCHK(hipMemset(c->B, 0, trc * 8));
+  HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
   HIPCHK(hipMemset(c->vn0, 0, 2 * lev * 8)); HIPCHK(hipMemset(c->dp, 0, lev * 8)); HIPCHK(hipMemset(c->divdp, 0, lev * 8));
   HIPCHK(hipMemset(c->divdp_proj, 0, lev * 8)); HIPCHK(hipMemset(c->eta, 0, (size_t)n * NLEVP * 16 * 8));
   HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
@@ -418,6 +427,17 @@ static int halo_exchange(tse_ctx* c, int nlyr, int kind = 0) {
   return 0;
 }
 
+// DSS on read: copy the received tracer halo behind the planes of the scratch field the next slab kernel gathers from
+static int unpack_halo(tse_ctx* c, double* field, int nlyr_halo) {
+  if (!c->ncol_recv) return 0;
+  const int nq = c->qsize * NLEV;
+  size_t tot = (size_t)c->ncol_recv * nq;
+  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->tps,
+                     c->nelemd);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // min/max over neighbours of qmin/qmax (in place; double-buffered on the device)
 static int neighbor_minmax(tse_ctx* c) {
   const int m = c->qsize * NLEV;
@@ -441,7 +461,8 @@ static int neighbor_minmax(tse_ctx* c) {
 // DSS (+ inverse mass matrix) of a tracer-sized field src -> dst, together with the extra level variable
 // (spheremp*var packed behind the tracers: nlyr = qsize*nlev + nlev as edgeAdv_p1, prim_advection_mod.F90:497,911-919)
 static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double* var /* [e][NLEV or NLEVP][16] */, int var_levels,
-                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0) {
+                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0,
+                               bool skip_tracers = false /* DSS on read: the next stage assembles the tracers itself */) {
   const int nq = c->qsize * NLEV;
   const double* var_src = var;
   if (var && var_levels != NLEV) {  // eta_dot_dpdn carries nlev+1 levels per element; DSS levels 1:nlev (:835-837)
@@ -451,33 +472,34 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
   if (c->ncol_send) {
     size_t tot = (size_t)c->ncol_send * nq;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, src,
-                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, 1);
+                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, c->tps);
     LAUNCH_CHECK();
     if (var) {
       size_t tv = (size_t)c->ncol_send * NLEV;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var_src,
-                         c->spheremp, c->sendbuf, nq + NLEV, nq, 0);
+                         c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0);
       LAUNCH_CHECK();
     }
   }
   if (halo_exchange(c, nq + NLEV)) return 1;
-  {
+  if (skip_tracers && unpack_halo(c, const_cast<double*>(src), nq + NLEV)) return 1;
+  if (!skip_tracers) {
     Scope s(c, "dss");
     const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-    const dim3 grid(8 * ((c->nelemd + 7) / 8) * nqc);
+    const dim3 grid(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd) * nqc);
     const dim3 grid2(8 * dss2_blocks_per_xcd(c->nelemd) * nqc);
     // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: (qsize*72 + 72) always is
     if (Qn0_avg)
       hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV, c->order, (const double*)c->dp, c->qmin2, c->qmax2);
+                         Qn0_avg, c->recvbuf, nq + NLEV, c->order, (const double*)c->dp, c->qmin2, c->qmax2, c->tps);
     else if (mode3) {
       DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = rdt; X.dp = c->dp; X.divdp_proj = c->divdp_proj; X.qmin = c->qmin; X.qmax = c->qmax;
-      X.lapout = c->B;
-      hipLaunchKernelGGL(k_dss_t<3>, grid, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+      X.lapout = c->B; X.tps = c->tps;
+      hipLaunchKernelGGL(k_dss_t<3>, grid, dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
                          (const double*)nullptr, c->recvbuf, nq + NLEV, X, c->order);
     } else
       hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr);
+                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr, c->tps);
     LAUNCH_CHECK();
   }
   if (var) {
@@ -495,8 +517,10 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
 }
 
 // one RK stage; fuse_avg: apply qdp_time_avg in the final DSS (whole-step path only)
+// gor ("gather on read", whole-step path only): stages 1 and 2 leave their pre-DSS scratch (T, then B) un-DSS'd and the
+// next stage's slab kernel assembles rspheremp*DSS(.) while reading it; the stage-3 Laplacian is handed over the same way.
 static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false,
-                           bool fused_mm = false) {
+                           bool fused_mm = false, bool gor = false) {
   if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
@@ -517,17 +541,46 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
     LAUNCH_CHECK();
   } else if (rhs == 1) {
     Scope s(c, "advance");
-    hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0);
+    if (gor)   // input: stage 1's scratch T (with its halo columns), output: B
+      hipLaunchKernelGGL((k_advance<1, 1>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)c->T,
+                         (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                         GatherArgs{c->dss_tab, c->rspheremp, c->tps});
+    else
+      hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+                         c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
+    LAUNCH_CHECK();
+  } else if (gor) {
+    const int nq = c->qsize * NLEV;
+    {   // input: stage 2's scratch B (+ halo); outputs: Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, qmin/qmax
+      Scope s(c, "lap");
+      hipLaunchKernelGGL(k_lap1<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, (const double*)c->B, c->T, c->dp,
+                         c->divdp_proj, c->qmin, c->qmax, Qnp1, GatherArgs{c->dss_tab, c->rspheremp, c->tps});
+      LAUNCH_CHECK();
+    }
+    if (neighbor_minmax(c)) return 1;   // before the Laplacian's halo exchange: k_advance reads that one out of recvbuf
+    if (c->ncol_send) {
+      size_t tot = (size_t)c->ncol_send * nq;
+      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->T,
+                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps);
+      LAUNCH_CHECK();
+    }
+    if (halo_exchange(c, nq)) return 1;
+    if (unpack_halo(c, c->T, nq)) return 1;
+    Scope s(c, "advance");
+    hipLaunchKernelGGL((k_advance<2, 2>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)Qnp1,
+                       (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                       GatherArgs{c->dss_tab, c->rspheremp, c->tps});
     LAUNCH_CHECK();
   } else {
+    c->t_zero_dirty = true;   // below, T receives rspheremp*DSS(lap) in the plain tracer layout
     if (!fused) {   // in the fused whole-step path the stage-2 DSS (k_dss_t<3>) has already produced B, qmin, qmax
       Scope s(c, "lap");
-      hipLaunchKernelGGL(k_lap1, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      hipLaunchKernelGGL(k_lap1<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax,
+                         (double*)nullptr, GatherArgs{nullptr, nullptr, c->tps});
       LAUNCH_CHECK();
     }
     // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1)
@@ -537,22 +590,22 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       // Laplacian and the bounds as two exchanges of the sizes the halo buffer is dimensioned for
       size_t tot = (size_t)c->ncol_send * nq;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->B,
-                         (const double*)nullptr, c->sendbuf, nq, 0, 1);
+                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps);
       LAUNCH_CHECK();
     }
     if (halo_exchange(c, nq)) return 1;
     {
       Scope s(c, "dss");
       const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-      const dim3 g2(8 * ((c->nelemd + 7) / 8) * nqc);
+      const dim3 g2(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd) * nqc);
       if (fused) {  // DSS + inverse mass + second Laplacian + biharmonic scaling in one pass: T = biharmonic term
-        DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = dt; X.nu_q = c->nu_q; X.dp0 = c->dp0;
-        hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(SLAB_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
+        DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = dt; X.nu_q = c->nu_q; X.dp0 = c->dp0; X.tps = c->tps;
+        hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
                            (const double*)nullptr, c->recvbuf, nq, X, c->order);
       } else {
         hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * dss2_blocks_per_xcd(c->nelemd) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
                            c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order, (const double*)nullptr, (double*)nullptr,
-                           (double*)nullptr);
+                           (double*)nullptr, c->tps);
       }
       LAUNCH_CHECK();
     }
@@ -560,16 +613,16 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     Scope s(c, "advance");
     if (fused)
       hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0);
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
     else
       hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0);
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
     LAUNCH_CHECK();
   }
-  const double* pre = rhs == 2 ? c->B : c->T;
+  const double* pre = (rhs == 2 || (gor && rhs == 1)) ? c->B : c->T;
   const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
   // fused path: the stage-2 DSS also forms Q = Qdp/dp for stage 3 (dp uses rhs_multiplier 2 and the stage dt)
-  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg, fused && rhs == 1, 2 * dt);
+  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg, fused && rhs == 1, 2 * dt, gor && rhs != 2);
 }
 
 int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
@@ -591,9 +644,14 @@ int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) 
   if (n0_qdp == np1_qdp) return fail("advec_tracers_remap_rk2: n0_qdp == np1_qdp");
   if (tse_compute_divdp(c)) return 1;
   const bool f = fuse_stage3();
-  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f, true)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, f)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, f)) return 1;
+  const bool gor = !f && dss_on_read() && c->tps * 8 < ((size_t)1 << 32);   // gather offsets are 32-bit bytes within a plane
+  if (gor && c->t_zero_dirty) {   // restore the all-zero element of every plane of T
+    HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * NLEV, c->tps * 8, 0, (size_t)16 * NLEV * 8, c->qsize, c->stream));
+    c->t_zero_dirty = false;
+  }
+  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f, true, gor)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, f, false, gor)) return 1;
+  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, f, false, gor)) return 1;
   c->mm_valid = np1_qdp;   // the final DSS emitted min/max of Qdp(np1)/dp for the next step
   return 0;
 }

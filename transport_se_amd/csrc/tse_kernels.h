@@ -1,7 +1,11 @@
 // tse_kernels.h -- the gfx950 kernels of the tracer hot path (included once by tse_api.hip).
 //
 // HBM layout (all fp64, point index p = j*4+i fastest):
-//   tracer fields  Qdp[tl][e][q][k][p], T[e][q][k][p] (pre-DSS scratch), B[e][q][k][p] (biharmonic scratch)
+//   tracer fields  Qdp[tl][e][q][k][p]
+//   pre-DSS scratch T, B: tracer-major planes, level fastest: T[q][slot], slot = (e*16+p)*NLEV + k for the local elements,
+//                  then one all-zero element (e = nelemd), then the received halo columns [col][k]; plane stride `tps`
+//                  doubles (tse_api.hip).  A plane is < 4 GB, so the DSS-on-read kernels address it with one uniform
+//                  base + 32-bit byte offsets.
 //   level fields   dp, divdp, divdp_proj, omega_p, dp3d [e][k][p]; vn0[e][k][c][p]; eta_dot_dpdn[e][73][p]
 //   bounds         qmin/qmax[e][q][k]
 //   metric         Dinv[e][p][4], metdet/rmetdet/spheremp/rspheremp[e][p]
@@ -32,6 +36,9 @@ __device__ __forceinline__ SlabId flat_slab(int nelemd) {
   return s;
 }
 inline int flat_blocks(int nelemd) { return 8 * ((nelemd * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
+
+// element index of T[q][e][p][k] in the tracer-major scratch layout
+__device__ __forceinline__ size_t t_idx(size_t tps, int q, int e, int p, int k) { return (size_t)q * tps + ((size_t)e * 16 + p) * NLEV + k; }
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
@@ -115,18 +122,84 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 }
 
 // ---------------------------------------------------------------------------------------------------
+// DSS on read.  In the whole-step path the DSS'd field between two RK stages is never written to memory: the consuming
+// slab kernel assembles rspheremp*DSS(T) for its own row from the producer's pre-DSS scratch T[e][q][p][k] -- the lane's 4
+// own points plus up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges,
+// then the corner) and the same inverse-mass multiply as k_dss_t2, so the value is bit-identical to what the DSS pass would
+// have stored.  That removes one read+write pass over the tracers per fused hand-over.
+struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; };
+// Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
+// per-load address arithmetic, 9 registers).  An empty table slot points into the all-zero element behind the local ones,
+// a remote slot into the halo columns that k_unpack_halo copied behind that, so all 12 loads are unconditional and alike.
+struct RowGather {
+  unsigned own;      // T[.][e][j*4][k]
+  unsigned go[8];    // the 8 contributions
+  double rs[4];
+};
+__device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, int nelemd, int e, int j, int k) {
+  constexpr int NS = 8;
+  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
+  R.own = (unsigned)(((e * 16 + j * 4) * NLEV + k) * 8);
+  int2 tt[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) tt[s] = A.tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const int2 t = tt[s];
+    unsigned slot = (unsigned)(nelemd * 16 * NLEV + k);                                    // the zero element
+    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * NLEV + k);
+    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * NLEV + (-(t.x + 2)) * NLEV + k);   // halo column -(t.x+2)
+    R.go[s] = slot * 8u;
+  }
+  load4(A.rspheremp + (size_t)e * 16 + j * 4, R.rs);
+}
+// loads only, all 12 in flight together; every use comes later.
+// The empty asm keeps the offsets opaque inside the tracer loop: otherwise their zero-extension is hoisted out of the loop
+// (18 registers instead of 9) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
+__device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q,
+                                             double v[4], double a[8]) {
+  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]), "+v"(R.go[3]), "+v"(R.go[4]), "+v"(R.go[5]), "+v"(R.go[6]),
+               "+v"(R.go[7]));
+  const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.tps);   // wave-uniform
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double*>(pq + (R.own + (unsigned)(i * NLEV * 8)));
+#pragma unroll
+  for (int s = 0; s < 8; s++) a[s] = *reinterpret_cast<const double*>(pq + R.go[s]);
+}
+__device__ __forceinline__ void gather_sum(const RowGather& R, const double v[4], const double a[8], double out[4]) {
+  double t0 = v[0] + a[0]; t0 = t0 + a[1]; t0 = t0 + a[2];
+  double t1 = v[1] + a[3];
+  double t2 = v[2] + a[4];
+  double t3 = v[3] + a[5]; t3 = t3 + a[6]; t3 = t3 + a[7];
+  out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
+  // the sums must be complete before the next tracer's loads are issued into v/a: pin them here (the compiler would
+  // otherwise sink the adds below the loads and keep a second copy of all 12 values)
+  asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : : "memory");
+}
+// received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
+__global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* __restrict__ recvbuf, int nlyr_halo, double* __restrict__ dst,
+                              size_t tps, int nelemd) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)ncol * nq) return;
+  const int col = (int)(t / nq), l = (int)(t % nq), q = l / NLEV, k = l - q * NLEV;
+  dst[(size_t)q * tps + (size_t)(nelemd + 1) * 16 * NLEV + (size_t)col * NLEV + k] = recvbuf[(size_t)col * nlyr_halo + l];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the fused euler_step advance (prim_advection_mod.F90:834-902) for one RK stage:
 //   Vstar = vn0/dp, dp_star = dp - dt*divdp, Qtens = Qdp - dt*div(Vstar*Qdp) [+ biharmonic], limiter8, *spheremp.
 // RHS = rhs_multiplier.  RHS==1 folds in the local min/max update (:781-793).  RHS==2 folds in the second
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
-template <int RHS>
+// GIN: DSS on read (whole-step path).  1: the tracer input is rspheremp*DSS of the previous stage's pre-DSS scratch (passed
+// in Qn0, layout T[e][q][p][k]); 2: the Laplacian input `lap` is (RHS == 2 only).
+template <int RHS, int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
-                                                          double* __restrict__ qmax, const double* __restrict__ dp0) {
+                                                          double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
   const SlabId sid = flat_slab(nelemd);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   // per-(e,k,row) constants, computed once and reused for every tracer:
@@ -168,10 +241,21 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   size_t so = ((size_t)e * qsize * NLEV + kc) * 16 + j * 4;
   size_t mi = (size_t)e * qsize * NLEV + kc;
   double qn[4], ls[4], minp, maxp;
-  load4(Qn0 + so, qn);
+  // DSS on read: the raw own/neighbour values of the next tracer are loaded into gv/ga as soon as the current tracer's have
+  // been summed (they are dead from then on), so the 12 loads fly during the divergence and the limiter
+  RowGather RG;
+  double gv[4], ga[8];
+  const double* gsrc = GIN == 1 ? Qn0 : lap;
+  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, gsrc, 0, gv, ga); }
+  if (GIN != 1) load4(Qn0 + so, qn);
   if (RHS == 3) load4(lap + so, ls);
   minp = qmin[mi]; maxp = qmax[mi];
   for (int q = 0; q < qsize; q++) {
+    if (GIN == 1) {
+      gather_sum(RG, gv, ga, qn);
+      __builtin_amdgcn_sched_barrier(0);   // sums first: the next tracer's loads reuse gv/ga (no second register set)
+      gather_issue(RG, GA, gsrc, q + 1 < qsize ? q + 1 : q, gv, ga);   // branch-free: the last iteration re-reads its own
+    }
     // software prefetch of the next tracer's slab row + bounds (vmcnt is in-order: issue everything for q+1 first)
     double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0, maxx = 0;
     double bih[4] = {0, 0, 0, 0};
@@ -180,13 +264,17 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
       // prefetched and the biharmonic term is formed first (its 40 VGPRs of metric constants are dead before the
       // divergence starts).  Deeper prefetch in the spare registers and forcing 3 waves/SIMD (35 spills) were both slower.
       double s0[4];
-      load4(lap + so, s0);
+      if (GIN == 2) {
+        gather_sum(RG, gv, ga, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        gather_issue(RG, GA, gsrc, q + 1 < qsize ? q + 1 : q, gv, ga);
+      } else load4(lap + so, s0);
       laplace_lean_row(D, L, s0, bih);
 #pragma unroll
       for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
     }
     if (q + 1 < qsize) {
-      load4(Qn0 + so + qstride, qnx);
+      if (GIN != 1) load4(Qn0 + so + qstride, qnx);
       if (RHS == 3) load4(lap + so + qstride, lsx);
       minx = qmin[mi + NLEV]; maxx = qmax[mi + NLEV];
     }
@@ -231,15 +319,15 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
     if (k < NLEV) {
-      // pre-DSS output in the gather-friendly layout T[e][q][p][k] (level fastest): the neighbours' edge points that
+      // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that
       // k_dss_t adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
-      double* tp = Tout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;
+      double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
 #pragma unroll
       for (int i = 0; i < 4; i++) tp[(size_t)i * NLEV] = x[i];
       if (j == 0) { qmin[mi] = minp; qmax[mi] = maxp; }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) { qn[i] = qnx[i]; ls[i] = lsx[i]; }
+    for (int i = 0; i < 4; i++) { if (GIN != 1) qn[i] = qnx[i]; ls[i] = lsx[i]; }
     minp = minx; maxp = maxx;
     so += qstride; mi += NLEV;
   }
@@ -248,10 +336,14 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // ---------------------------------------------------------------------------------------------------
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
+// GIN == 1 (whole-step path): Qn0 is the stage-2 pre-DSS scratch T[e][q][p][k]; the DSS'd Qdp is assembled on read and
+// also stored to Qout (stage 3 reads it again in k_advance).
+template <int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
-                                                       double* __restrict__ qmin, double* __restrict__ qmax) {
+                                                       double* __restrict__ qmin, double* __restrict__ qmax, double* __restrict__ Qout,
+                                                       GatherArgs GA) {
   const SlabId sid = flat_slab(nelemd);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   LapGeo L;
@@ -265,17 +357,25 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
 #pragma unroll
   for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
+  RowGather RG;
+  double gv[4], ga[8];
+  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, gv, ga); }
   for (int q = 0; q < qsize; q++) {
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
     double x[4], l1[4];
-    load4(Qn0 + so, x);
+    if (GIN) {
+      gather_sum(RG, gv, ga, x);
+      __builtin_amdgcn_sched_barrier(0);
+      gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, gv, ga);
+      if (k < NLEV) store4(Qout + so, x);
+    } else load4(Qn0 + so, x);
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
     double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     laplace_lean_row(D, L, x, l1);
     if (k < NLEV) {
-      double* bp = Bout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;   // B[e][q][p][k], as T
+      double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);   // scratch layout, as T
 #pragma unroll
       for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
       if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
@@ -348,7 +448,7 @@ __global__ __launch_bounds__(DSS_THREADS) void k_dss(int nelemd, int nlyr, int n
   if (active) store4(dst + off, v);
 }
 
-// Tracer-field DSS: source in the level-fastest layout src[e][q][p][k] written by k_advance/k_lap1, destination in the
+// Tracer-field DSS: source in the level-fastest scratch layout src[q][e][p][k] written by k_advance/k_lap1, destination in the
 // standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
 // k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
 // Work items are ordered tracer-chunk-major and the 8 XCDs each walk a contiguous range of elements (see k_dss).
@@ -364,19 +464,35 @@ struct DssExtra {
   double dt, nu_q;                 // MODE 2: stage dt ; MODE 3: rdt = 2*dt in `dt`
   const double* dp0;               // MODE 2
   const double* dp; const double* divdp_proj; double* qmin; double* qmax; double* lapout;   // MODE 3
+  size_t tps;                      // plane stride of the scratch layout (all modes)
 };
-template <int MODE>
-__global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
-                                                        const double* __restrict__ rspheremp, const double* __restrict__ src,
-                                                        double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                        const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X,
-                                                        const int* __restrict__ order) {
-  const int S8 = (nelemd + 7) >> 3;
+// Lane mapping shared by the tracer DSS kernels: work = (tracer chunk, XCD range of elements, flattened (element slot,
+// unit)) with UNITS lanes per element.  288 (or 144) lanes per element do not fill whole waves, so the lanes of a block run
+// across element boundaries: no idle lanes except in a range's last block, and blocks of 4 waves instead of 5.
+constexpr int DSS_FLAT_THREADS = 256;
+template <int UNITS>
+inline int dss_blocks_per_xcd(int nelemd) { return (((nelemd + 7) >> 3) * UNITS + DSS_FLAT_THREADS - 1) / DSS_FLAT_THREADS; }
+struct DssLane { int slot, r, qc; bool live; };
+template <int UNITS>
+__device__ __forceinline__ DssLane dss_lane(int nelemd) {
+  const int S8 = (nelemd + 7) >> 3;                                             // elements per XCD range (as in `order`)
+  const int B8 = (S8 * UNITS + DSS_FLAT_THREADS - 1) / DSS_FLAT_THREADS;        // blocks per XCD range and tracer chunk
   const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
-  const int slot = xcd * S8 + it % S8, qc = it / S8;
-  if (slot >= nelemd) return;
-  const int e = order[slot];   // walk order inside the XCD's element range: neighbours close in time (tse_api.hip)
-  const int tid = threadIdx.x, k = tid >> 2, j = tid & 3, kc = k < NLEV ? k : NLEV - 1;
+  const int bi = it % B8, g = bi * DSS_FLAT_THREADS + threadIdx.x, idx = g / UNITS;
+  DssLane l;
+  l.qc = it / B8; l.r = g - idx * UNITS; l.slot = xcd * S8 + idx; l.live = idx < S8 && l.slot < nelemd;
+  return l;
+}
+template <int MODE>
+__global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
+                                                            const double* __restrict__ rspheremp, const double* __restrict__ src,
+                                                            double* __restrict__ dst, const double* __restrict__ Qn0,
+                                                            const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X,
+                                                            const int* __restrict__ order) {
+  const DssLane ln = dss_lane<NLEV * 4>(nelemd);
+  if (!ln.live) return;
+  const int e = order[ln.slot];   // walk order inside the XCD's element range: neighbours close in time (tse_api.hip)
+  const int qc = ln.qc, k = ln.r >> 2, j = ln.r & 3, kc = k;
   // Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take up to 3 contributions
   // (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot re-reads the
   // lane's own value and is weighted 0) so that the 8 loads are in flight together -- a load inside a divergent
@@ -386,14 +502,14 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
   const double* gp[NS];   // address of the contribution for tracer q0, level kc
   unsigned gvalid = 0, gremote = 0;   // bit s: slot populated / comes from the halo buffer (tracer stride NLEV)
   const int q0 = qc * qb;
-  const double* own0 = src + (((size_t)e * qsize + q0) * 16 + j * 4) * NLEV + kc;
+  const double* own0 = src + t_idx(X.tps, q0, e, j * 4, kc);
   int2 tt[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];   // 8 loads in flight together
 #pragma unroll
   for (int s = 0; s < NS; s++) {
     const int2 t = tt[s];
-    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + kc; gvalid |= 1u << s; }
+    if (t.x >= 0) { gp[s] = src + t_idx(X.tps, q0, t.x, t.y, kc); gvalid |= 1u << s; }
     else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + kc; gvalid |= 1u << s; gremote |= 1u << s; }
     else gp[s] = own0;
   }
@@ -421,13 +537,13 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
     const size_t dq = (size_t)(q - q0);
     double v[4], a[NS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = own0[dq * 16 * NLEV + (size_t)i * NLEV];
+    for (int i = 0; i < 4; i++) v[i] = own0[dq * X.tps + (size_t)i * NLEV];
 #pragma unroll
     for (int s = 0; s < NS; s++) a[s] = 0.0;
     // loads only (predicated per lane); every use comes after the last load so that no wait lands between them
 #pragma unroll
     for (int s = 0; s < NS; s++)
-      if (gvalid & (1u << s)) a[s] = gp[s][dq * ((gremote & (1u << s)) ? NLEV : 16 * NLEV)];
+      if (gvalid & (1u << s)) a[s] = gp[s][dq * ((gremote & (1u << s)) ? (size_t)NLEV : X.tps)];
     // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
     v[0] = v[0] + a[0]; v[0] = v[0] + a[1]; v[0] = v[0] + a[2];
     v[1] = v[1] + a[3];
@@ -457,7 +573,7 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
       double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
       laplace_lean_row(X.D, L, x, l1);
       if (k < NLEV) {
-        double* bp = X.lapout + (((size_t)e * qsize + q) * 16 + j * 4) * NLEV + k;
+        double* bp = X.lapout + t_idx(X.tps, q, e, j * 4, k);
 #pragma unroll
         for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
         if (j == 0) { X.qmin[((size_t)e * qsize + q) * NLEV + k] = mn; X.qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
@@ -470,28 +586,21 @@ __global__ __launch_bounds__(SLAB_THREADS) void k_dss_t(int nelemd, int qsize, i
 // a 16-byte load (the level-fastest source makes the level pair contiguous).  The 8-byte version spent as much time
 // issuing the 12 loads per tracer as moving the data (a variant whose gathers all hit the lane's own element in L1 was
 // as slow as the real one).
-constexpr int DSS2_THREADS = 256;
+constexpr int DSS2_THREADS = DSS_FLAT_THREADS;
 constexpr int DSS2_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs x 4 rows
-inline int dss2_blocks_per_xcd(int nelemd) { return (((nelemd + 7) >> 3) * DSS2_UNITS + DSS2_THREADS - 1) / DSS2_THREADS; }
+inline int dss2_blocks_per_xcd(int nelemd) { return dss_blocks_per_xcd<DSS2_UNITS>(nelemd); }
 template <int MODE>
 __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
                                                          const double* __restrict__ rspheremp, const double* __restrict__ src,
                                                          double* __restrict__ dst, const double* __restrict__ Qn0,
                                                          const double* __restrict__ recvbuf, int nlyr_halo,
                                                          const int* __restrict__ order, const double* __restrict__ dpnext,
-                                                         double* __restrict__ mn_out, double* __restrict__ mx_out) {
+                                                         double* __restrict__ mn_out, double* __restrict__ mx_out, size_t tps) {
   // mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
   // next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
-  // Work = (tracer chunk, XCD range of elements, flattened (element slot, level pair, row)): 144 lanes per element do not
-  // fill whole waves, so the lanes of a block run across element boundaries (no idle lanes except in a range's last block).
-  const int S8 = (nelemd + 7) >> 3;                                         // elements per XCD range (as in `order`)
-  const int B8 = (S8 * DSS2_UNITS + DSS2_THREADS - 1) / DSS2_THREADS;       // blocks per XCD range and tracer chunk
-  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
-  const int bi = it % B8, qc = it / B8;
-  const int g = bi * DSS2_THREADS + threadIdx.x;
-  const int idx = g / DSS2_UNITS, r = g - idx * DSS2_UNITS;
-  const int slot = xcd * S8 + idx;
-  if (idx >= S8 || slot >= nelemd) return;
+  const DssLane ln = dss_lane<DSS2_UNITS>(nelemd);
+  if (!ln.live) return;
+  const int slot = ln.slot, r = ln.r, qc = ln.qc;
   const int e = order[slot];
   const int k0 = (r >> 2) * 2, j = r & 3;            // levels k0, k0+1
   constexpr int NS = 8;
@@ -499,14 +608,14 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
   const double* gp[NS];
   unsigned gvalid = 0, gremote = 0;
   const int q0 = qc * qb;
-  const double* own0 = src + (((size_t)e * qsize + q0) * 16 + j * 4) * NLEV + k0;
+  const double* own0 = src + t_idx(tps, q0, e, j * 4, k0);
   int2 tt[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
 #pragma unroll
   for (int s = 0; s < NS; s++) {
     const int2 t = tt[s];
-    if (t.x >= 0) { gp[s] = src + (((size_t)t.x * qsize + q0) * 16 + t.y) * NLEV + k0; gvalid |= 1u << s; }
+    if (t.x >= 0) { gp[s] = src + t_idx(tps, q0, t.x, t.y, k0); gvalid |= 1u << s; }
     else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + k0; gvalid |= 1u << s; gremote |= 1u << s; }
     else gp[s] = own0;
   }
@@ -522,12 +631,12 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
     const size_t dq = (size_t)(q - q0);
     double2 v[4], a[NS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * 16 * NLEV + (size_t)i * NLEV);
+    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * tps + (size_t)i * NLEV);
 #pragma unroll
     for (int s = 0; s < NS; s++) a[s] = make_double2(0.0, 0.0);
 #pragma unroll
     for (int s = 0; s < NS; s++)
-      if (gvalid & (1u << s)) a[s] = *reinterpret_cast<const double2*>(gp[s] + dq * ((gremote & (1u << s)) ? NLEV : 16 * NLEV));
+      if (gvalid & (1u << s)) a[s] = *reinterpret_cast<const double2*>(gp[s] + dq * ((gremote & (1u << s)) ? (size_t)NLEV : tps));
     // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
 #define ADD2(vi, as) do { vi.x = vi.x + as.x; vi.y = vi.y + as.y; } while (0)
     ADD2(v[0], a[0]); ADD2(v[0], a[1]); ADD2(v[0], a[2]);
@@ -565,13 +674,12 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
-                       int transposed /* src[e][q][p][k] instead of [e][lyr][p] */) {
+                       size_t tps /* > 0: src is a scratch field (plane stride tps) instead of [e][lyr][p] */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nlyr) return;
   int col = (int)(t / nlyr), l = (int)(t % nlyr);
   int2 s = send_src[col];
-  double a = transposed ? src[(((size_t)s.x * (nlyr / NLEV) + l / NLEV) * 16 + s.y) * NLEV + l % NLEV]
-                        : src[((size_t)s.x * nlyr + l) * 16 + s.y];
+  double a = tps ? src[t_idx(tps, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * nlyr + l) * 16 + s.y];
   if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
   sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
 }
