@@ -55,7 +55,8 @@ int main(int argc, char** argv) {
   }
   Dvv_t D; double dv[16] = {-3, -0.809, 0.309, -0.5, 4.045, 0, -1.118, 1.545, -1.545, 1.118, 0, -4.045, 0.5, -0.309, 0.809, 3};
   for (int i = 0; i < 16; i++) D.d[i] = dv[i];
-  GeoPtrs G{Dinv, m1, m2, m3, m4};
+  double* dvvd; CK(hipMalloc(&dvvd, 128)); CK(hipMemcpy(dvvd, dv, 128, hipMemcpyHostToDevice));
+  GeoPtrs G{Dinv, m1, m2, m3, m4, dvvd};
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   auto timeit = [&](const char* name, double bytes, auto launch) {
     launch(); CK(hipDeviceSynchronize());
@@ -66,8 +67,8 @@ int main(int argc, char** argv) {
   double fb = trc * 8.0;
   timeit("copy_stream (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_stream, dim3(256 * 8), dim3(256), 0, 0, trc / 2, (const double2*)Q, (double2*)T); });
   timeit("copy_slab (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_slab, dim3(nelem), dim3(SLAB_THREADS), 0, 0, qsize, Q, T); });
-  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); });
-  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); });
+  timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); });
+  timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); });
   // DSS variants: synthetic regular topology W:e-1 E:e+1 S:e-ne N:e+ne (mod nelem)
   {
     std::vector<int2> tab((size_t)nelem * 48, make_int2(-1, 0)), tab0 = tab;
@@ -105,7 +106,7 @@ int main(int argc, char** argv) {
       hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
       int nqc = (qsize + 4) / 5;
       dim3 g2(8 * dss2_blocks_per_xcd(nelem) * nqc);
-      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{}); };
+      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); };
       auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder, (const double*)nullptr, (double*)nullptr, (double*)nullptr); };
       timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });
       timeit("adv<1> then dss (serial)", 4 * fb, [&] { adv(0); dss(0); });

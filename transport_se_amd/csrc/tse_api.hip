@@ -75,10 +75,14 @@ struct tse_ctx {
   size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
-  GeoPtrs geo() const { return GeoPtrs{Dinv, metdet, rmetdet, spheremp, rspheremp}; }
+  double* dvv_d = nullptr;   // device copy of Dvv
+  GeoPtrs geo() const { return GeoPtrs{Dinv, metdet, rmetdet, spheremp, rspheremp, dvv_d}; }
 };
 
 const char* tse_last_error(void) { return g_err; }
+
+// element walk order of the slab kernels: plain element order; TSE_SLAB_ORDER=1 = the DSS strip walk (measured: no gain)
+static const int* slab_order(tse_ctx* c) { const char* e = getenv("TSE_SLAB_ORDER"); return (e && e[0] == '1') ? c->order : nullptr; }
 
 template <class T>
 static int dalloc(T** p, size_t n) {
@@ -143,6 +147,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   c->nelemd = a->nelemd; c->qsize = a->qsize; c->nu_q = a->nu_q; c->ps0 = a->ps0; c->rsplit = a->rsplit;
   c->exchange = a->exchange; c->exchange_user = a->exchange_user;
   memcpy(c->D.d, a->Dvv, sizeof c->D.d);
+  { std::vector<double> dv(a->Dvv, a->Dvv + 16); if (upload(&c->dvv_d, dv)) return 1; }
   HIPCHK(hipStreamCreate(&c->stream));
   const int n = a->nelemd;
   std::vector<double> h;
@@ -318,7 +323,7 @@ void tse_finalize(tse_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
+  void* ptrs[] = {c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->lvl_tmp2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -541,24 +546,24 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
     LAUNCH_CHECK();
   } else if (rhs == 1) {
     Scope s(c, "advance");
     if (gor)   // input: stage 1's scratch T (with its halo columns), output: B
       hipLaunchKernelGGL((k_advance<1, 1>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)c->T,
                          (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                         GatherArgs{c->dss_tab, c->rspheremp, c->tps});
+                         GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
     else
       hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                         c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
+                         c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
     LAUNCH_CHECK();
   } else if (gor) {
     const int nq = c->qsize * NLEV;
     {   // input: stage 2's scratch B (+ halo); outputs: Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, qmin/qmax
       Scope s(c, "lap");
       hipLaunchKernelGGL(k_lap1<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, (const double*)c->B, c->T, c->dp,
-                         c->divdp_proj, c->qmin, c->qmax, Qnp1, GatherArgs{c->dss_tab, c->rspheremp, c->tps});
+                         c->divdp_proj, c->qmin, c->qmax, Qnp1, GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
       LAUNCH_CHECK();
     }
     if (neighbor_minmax(c)) return 1;   // before the Laplacian's halo exchange: k_advance reads that one out of recvbuf
@@ -573,14 +578,14 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     Scope s(c, "advance");
     hipLaunchKernelGGL((k_advance<2, 2>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)Qnp1,
                        (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                       GatherArgs{c->dss_tab, c->rspheremp, c->tps});
+                       GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
     LAUNCH_CHECK();
   } else {
     c->t_zero_dirty = true;   // below, T receives rspheremp*DSS(lap) in the plain tracer layout
     if (!fused) {   // in the fused whole-step path the stage-2 DSS (k_dss_t<3>) has already produced B, qmin, qmax
       Scope s(c, "lap");
       hipLaunchKernelGGL(k_lap1<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax,
-                         (double*)nullptr, GatherArgs{nullptr, nullptr, c->tps});
+                         (double*)nullptr, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
       LAUNCH_CHECK();
     }
     // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1)
@@ -613,10 +618,10 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     Scope s(c, "advance");
     if (fused)
       hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
     else
       hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps});
+                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
     LAUNCH_CHECK();
   }
   const double* pre = (rhs == 2 || (gor && rhs == 1)) ? c->B : c->T;

@@ -53,7 +53,10 @@ struct RowGeo {
   double drow[4];  // drow[m] = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
 };
 
-__device__ __forceinline__ void load_row_geo(RowGeo& g, const Dvv_t& D, const double* __restrict__ Dinv,
+// dvv: a device copy of Dvv.  The lane's column/row of Dvv are loaded from it rather than selected out of the by-value
+// kernel argument: a select chain over D.d[] by the lane's j is turned into a dynamically indexed read of D, which puts D
+// into scratch memory and its 16 values into 32 VGPRs for the whole kernel (instead of SGPRs).
+__device__ __forceinline__ void load_row_geo(RowGeo& g, const double* __restrict__ dvv, const double* __restrict__ Dinv,
                                              const double* __restrict__ metdet, const double* __restrict__ rmetdet,
                                              const double* __restrict__ spheremp, int e, int j) {
   const double* di = Dinv + ((size_t)e * 16 + j * 4) * 4;
@@ -65,11 +68,9 @@ __device__ __forceinline__ void load_row_geo(RowGeo& g, const Dvv_t& D, const do
   load4(metdet + (size_t)e * 16 + j * 4, g.metdet);
   load4(rmetdet + (size_t)e * 16 + j * 4, g.rmetdet);
   load4(spheremp + (size_t)e * 16 + j * 4, g.spheremp);
+  load4(dvv + j * 4, g.dcol);
 #pragma unroll
-  for (int m = 0; m < 4; m++) {
-    g.dcol[m] = j == 0 ? D.d[m] : j == 1 ? D.d[4 + m] : j == 2 ? D.d[8 + m] : D.d[12 + m];
-    g.drow[m] = j == 0 ? D.d[m * 4] : j == 1 ? D.d[m * 4 + 1] : j == 2 ? D.d[m * 4 + 2] : D.d[m * 4 + 3];
-  }
+  for (int m = 0; m < 4; m++) g.drow[m] = dvv[m * 4 + j];
 }
 
 // dx[l] = sum_i Dvv(i,l) a[i]  (in-register) ;  dy[i] = sum_m Dvv(m,j) b(i,m)  (quad broadcast of rows)

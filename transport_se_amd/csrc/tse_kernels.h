@@ -26,13 +26,18 @@ constexpr int FLAT_THREADS = 256;
 // XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[e][q][p][:]
 // rows through the same L2 (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
 struct SlabId { int e, k; bool live; };
-__device__ __forceinline__ SlabId flat_slab(int nelemd) {
+// `order` (optional): the strip walk of tse_api.hip -- consecutive slots are elements that are neighbours in both directions,
+// so that the ~60 elements an XCD works on at a time form a compact patch and the DSS-on-read gathers of one element hit
+// lines its neighbours are reading at the same moment (L2) instead of going to HBM for the north/south edges.
+__device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ order = nullptr) {
   const int per = gridDim.x >> 3, lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   SlabId s;
   s.live = gs < n;
   const int g = s.live ? gs : n - 1;   // idle tail lanes recompute the last slab and store nothing
-  s.e = g / NLEV; s.k = g - s.e * NLEV;
+  const int slot = g / NLEV;
+  s.k = g - slot * NLEV;
+  s.e = order ? order[slot] : slot;
   return s;
 }
 inline int flat_blocks(int nelemd) { return 8 * ((nelemd * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
@@ -42,6 +47,7 @@ __device__ __forceinline__ size_t t_idx(size_t tps, int q, int e, int p, int k) 
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
+  const double* dvv;   // device copy of deriv%Dvv (see load_row_geo)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_divdp(int nelemd, Dvv_t D, Geo
   const SlabId sid = flat_slab(nelemd);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   RowGeo g;
-  load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
   double v1[4], v2[4], div[4];
   load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, v1);
   load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, v2);
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 // own points plus up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges,
 // then the corner) and the same inverse-mass multiply as k_dss_t2, so the value is bit-identical to what the DSS pass would
 // have stored.  That removes one read+write pass over the tracers per fused hand-over.
-struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; };
+struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const int* order; };
 // Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
 // per-load address arithmetic, 9 registers).  An empty table slot points into the all-zero element behind the local ones,
 // a remote slot into the halo columns that k_unpack_halo copied behind that, so all 12 loads are unconditional and alike.
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
-  const SlabId sid = flat_slab(nelemd);
+  const SlabId sid = flat_slab(nelemd, GA.order);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   LapGeo L;  // only used by the Laplacian of stage 3 (RHS == 2)
   {
     RowGeo g;
-    load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+    load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
     const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
     double dpk[4], vs1[4], vs2[4], t0[4], t1[4];
     load4(dp + lo, dpk); load4(divdp_proj + lo, t0); load4(divdp + lo, t1);
@@ -344,12 +350,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax, double* __restrict__ Qout,
                                                        GatherArgs GA) {
-  const SlabId sid = flat_slab(nelemd);
+  const SlabId sid = flat_slab(nelemd, GA.order);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   LapGeo L;
   {
     RowGeo g;
-    load_row_geo(g, D, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+    load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
     make_lap_geo(L, g);
   }
   const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
@@ -360,27 +366,60 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   RowGather RG;
   double gv[4], ga[8];
   if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, gv, ga); }
-  for (int q = 0; q < qsize; q++) {
-    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
-    double x[4], l1[4];
-    if (GIN) {
-      gather_sum(RG, gv, ga, x);
-      __builtin_amdgcn_sched_barrier(0);
-      gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, gv, ga);
-      if (k < NLEV) store4(Qout + so, x);
-    } else load4(Qn0 + so, x);
+  if (!GIN) {
+    for (int q = 0; q < qsize; q++) {
+      const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
+      double x[4], l1[4];
+      load4(Qn0 + so, x);
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
-    double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
-    double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
-    laplace_lean_row(D, L, x, l1);
-    if (k < NLEV) {
-      double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);   // scratch layout, as T
+      for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
+      double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
+      double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+      laplace_lean_row(D, L, x, l1);
+      if (k < NLEV) {
+        double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);   // scratch layout, as T
 #pragma unroll
-      for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
-      if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
+        for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
+        if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
+      }
     }
+    return;
   }
+  // DSS on read.  Memory schedule of one tracer step (gfx950: one counter for loads and stores, which return out of order
+  // between the two kinds, so a wait for loads also drains every store issued before it; and a store's data registers may
+  // not be overwritten until it has completed):
+  //   wait for this tracer's gather -> sum -> issue the PREVIOUS tracer's stores -> issue the NEXT tracer's gather -> compute.
+  // The results go to a second register set (A/B alternate), so that the stores issued at the top of a step drain during
+  // the whole step and nothing waits for them.
+  struct Out { double q[4], l[4], mn, mx; };
+  auto put = [&](const Out& o, int q) {   // stores of tracer q
+    if (k < NLEV) {
+      store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
+      double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);
+#pragma unroll
+      for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = o.l[i];
+      if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = o.mn; qmax[((size_t)e * qsize + q) * NLEV + k] = o.mx; }
+    }
+  };
+  auto step = [&](int q, const Out* prev, Out& cur) {
+    double x[4];
+    gather_sum(RG, gv, ga, x);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prev) put(*prev, q - 1);
+    gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, gv, ga);   // branch-free: the last step re-reads its own tracer
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cur.q[i] = x[i]; x[i] = x[i] * dpk[i]; }
+    cur.mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
+    cur.mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+    laplace_lean_row(D, L, x, cur.l);
+  };
+  Out A, B;
+  step(0, nullptr, A);
+  int q = 1;
+  for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
+  if (q < qsize) { step(q, &A, B); put(B, q); }
+  else put(A, q - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -519,7 +558,7 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_t(int nelemd, int qsiz
   double visc[4] = {0, 0, 0, 0}, rdpk[4] = {0, 0, 0, 0};
   if (MODE == 2 || MODE == 3) {
     RowGeo g;
-    load_row_geo(g, X.D, X.G.Dinv, X.G.metdet, X.G.rmetdet, X.G.spheremp, e, j);
+    load_row_geo(g, X.G.dvv, X.G.Dinv, X.G.metdet, X.G.rmetdet, X.G.spheremp, e, j);
     make_lap_geo(L, g);
     if (MODE == 2) {
 #pragma unroll
