@@ -199,7 +199,9 @@ __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* _
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 // GIN: DSS on read (whole-step path).  1: the tracer input is rspheremp*DSS of the previous stage's pre-DSS scratch (passed
 // in Qn0, layout T[e][q][p][k]); 2: the Laplacian input `lap` is (RHS == 2 only).
-template <int RHS, int GIN = 0>
+// Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
+// (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
+template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
 __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
@@ -243,46 +245,60 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 #pragma unroll
   for (int i = 0; i < 4; i++) visc[i] = RHS == 2 ? (-3.0 * dt * nu_q * dp0[kc]) / spm[i] : 0.0;  // -rhs_viss*dt*nu_q*dp0/spheremp
 
-  const size_t qstride = (size_t)NLEV * 16;
-  size_t so = ((size_t)e * qsize * NLEV + kc) * 16 + j * 4;
-  size_t mi = (size_t)e * qsize * NLEV + kc;
-  double qn[4], ls[4], minp, maxp;
-  // DSS on read: the raw own/neighbour values of the next tracer are loaded into gv/ga as soon as the current tracer's have
-  // been summed (they are dead from then on), so the 12 loads fly during the divergence and the limiter
-  RowGather RG;
-  double gv[4], ga[8];
-  const double* gsrc = GIN == 1 ? Qn0 : lap;
-  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, gsrc, 0, gv, ga); }
-  if (GIN != 1) load4(Qn0 + so, qn);
-  if (RHS == 3) load4(lap + so, ls);
-  minp = qmin[mi]; maxp = qmax[mi];
-  for (int q = 0; q < qsize; q++) {
-    if (GIN == 1) {
-      gather_sum(RG, gv, ga, qn);
-      __builtin_amdgcn_sched_barrier(0);   // sums first: the next tracer's loads reuse gv/ga (no second register set)
-      gather_issue(RG, GA, gsrc, q + 1 < qsize ? q + 1 : q, gv, ga);   // branch-free: the last iteration re-reads its own
+  // Memory schedule of one tracer step (gfx950: loads and stores share one counter and return out of order between the
+  // two kinds, so a wait for loads also drains every store issued before it; and a store's data registers may not be
+  // overwritten until it has completed):
+  //   wait for this tracer's inputs -> issue the PREVIOUS tracer's stores -> issue the NEXT tracer's loads -> compute.
+  // With DB the results go to a second register set (A/B alternate): the stores issued at the top of a step then have the
+  // whole step to drain and nothing waits for them (worth its 12 registers where few waves fit: the DSS-on-read kernels).
+  struct Out { double x[4], mn, mx; };
+  auto put = [&](const Out& o, int q) {
+    if (k < NLEV) {
+      // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
+      // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
+      double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
+#pragma unroll
+      for (int i = 0; i < 4; i++) tp[(size_t)i * NLEV] = o.x[i];
+      if (j == 0) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
     }
-    // software prefetch of the next tracer's slab row + bounds (vmcnt is in-order: issue everything for q+1 first)
-    double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0, maxx = 0;
+  };
+  RowGather RG;
+  double gv[4], ga[8];                                   // raw own/neighbour values of the gathered input (DSS on read)
+  double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
+  const double* gsrc = GIN == 1 ? Qn0 : lap;
+  auto fetch = [&](int q) {   // loads only
+    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = ((size_t)e * qsize + q) * NLEV + kc;
+    if (GIN) gather_issue(RG, GA, gsrc, q, gv, ga);
+    if (GIN != 1) load4(Qn0 + so, qnx);
+    if (RHS == 3 || (RHS == 2 && GIN != 2)) load4(lap + so, lsx);
+    minx = qmin[mi]; maxx = qmax[mi];
+  };
+  if (GIN) gather_setup(RG, GA, nelemd, e, j, kc);
+  fetch(0);
+  auto step = [&](int q, const Out* prev, Out& cur) {
+    double qn[4], ls[4] = {0, 0, 0, 0}, minp = minx, maxp = maxx;
+    if (GIN == 1) gather_sum(RG, gv, ga, qn);
+    else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) qn[i] = qnx[i];
+      asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
+    }
+    if (RHS == 2 && GIN == 2) gather_sum(RG, gv, ga, ls);
+    else if (RHS >= 2) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) ls[i] = lsx[i];
+      asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]) : : "memory");
+    }
+    asm volatile("" : "+v"(minp), "+v"(maxp) : : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (prev) put(*prev, q - 1);
+    fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
+    __builtin_amdgcn_sched_barrier(0);
     double bih[4] = {0, 0, 0, 0};
-    if (RHS == 2) {
-      // stage 3 with the second Laplacian in-kernel: register-bound (2 waves/SIMD), so the Laplacian input is not
-      // prefetched and the biharmonic term is formed first (its 40 VGPRs of metric constants are dead before the
-      // divergence starts).  Deeper prefetch in the spare registers and forcing 3 waves/SIMD (35 spills) were both slower.
-      double s0[4];
-      if (GIN == 2) {
-        gather_sum(RG, gv, ga, s0);
-        __builtin_amdgcn_sched_barrier(0);
-        gather_issue(RG, GA, gsrc, q + 1 < qsize ? q + 1 : q, gv, ga);
-      } else load4(lap + so, s0);
-      laplace_lean_row(D, L, s0, bih);
+    if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
+      laplace_lean_row(D, L, ls, bih);
 #pragma unroll
       for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
-    }
-    if (q + 1 < qsize) {
-      if (GIN != 1) load4(Qn0 + so + qstride, qnx);
-      if (RHS == 3) load4(lap + so + qstride, lsx);
-      minx = qmin[mi + NLEV]; maxx = qmax[mi + NLEV];
     }
     double gv1[4], gv2[4], x[4], dx[4], dy[4];
 #pragma unroll
@@ -290,10 +306,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     // d/dx in-register, d/dy across the quad (deriv_xy with the lane's dcol)
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-      double s = 0.0;
+      double sm = 0.0;
 #pragma unroll
-      for (int i = 0; i < 4; i++) s = s + D.d[l * 4 + i] * gv1[i];
-      dx[l] = s;
+      for (int i = 0; i < 4; i++) sm = sm + D.d[l * 4 + i] * gv1[i];
+      dx[l] = sm;
     }
     {
       double r0[4], r1[4], r2[4], r3[4];
@@ -323,19 +339,18 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
     limiter8_quad(x, c, sumc, minp, maxp);
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
-    if (k < NLEV) {
-      // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that
-      // k_dss_t adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
-      double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
-#pragma unroll
-      for (int i = 0; i < 4; i++) tp[(size_t)i * NLEV] = x[i];
-      if (j == 0) { qmin[mi] = minp; qmax[mi] = maxp; }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) { if (GIN != 1) qn[i] = qnx[i]; ls[i] = lsx[i]; }
-    minp = minx; maxp = maxx;
-    so += qstride; mi += NLEV;
+    for (int i = 0; i < 4; i++) cur.x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
+    cur.mn = minp; cur.mx = maxp;
+  };
+  Out A, B;
+  if (DB) {
+    step(0, nullptr, A);
+    int q = 1;
+    for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
+    if (q < qsize) { step(q, &A, B); put(B, q); }
+    else put(A, q - 1);
+  } else {   // plenty of waves (4 per SIMD): store at the end of the step, 12 registers less
+    for (int q = 0; q < qsize; q++) { step(q, nullptr, A); put(A, q); }
   }
 }
 
