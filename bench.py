@@ -22,9 +22,14 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_DOF_STEP = 400.0 / 3.0   # 16 2/3 mandatory fp64 field passes per tracer step
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# algorithmic bytes per DOF of ONE launch of each kernel group (DESIGN.md "kernels"): fields read + written * 8 B
-KERNEL_BYTES_PER_DOF = {"advance": (16.0 + 16.0 + 24.0) / 3.0, "dss": (16.0 + 16.0 + 16.0 + 24.0) / 4.0,
-                        "lap": 16.0, "minmax": 8.0, "remap": 16.0}
+# algorithmic bytes per DOF of ONE launch of each kernel (DESIGN.md "kernels"): tracer fields read + written, 8 B each.
+# Default path (DSS on read): advance0 = k_advance<0> (Qdp -> T), advance1 = k_advance<1,1> (T -> B), lap = k_lap1<1>
+# (B -> Qdp(np1), Laplacian), advance2 = k_advance<2,2> (Qdp(np1), Laplacian -> B), dss = k_dss_t2<1> (B, Qdp(n0) -> Qdp(np1)).
+KERNEL_BYTES_PER_DOF = {"advance0": 16.0, "advance1": 16.0, "lap": 24.0, "advance2": 24.0, "dss": 24.0, "remap": 16.0}
+if os.environ.get("TSE_DSS_ON_READ", "1") == "0":   # one DSS pass per stage: 4 dss launches (3 x 16 + 24), lap = k_lap1<0>
+    KERNEL_BYTES_PER_DOF.update({"lap": 16.0, "dss": (16.0 + 16.0 + 16.0 + 24.0) / 4.0})
+KERNEL_NAMES = {"advance0": "k_advance<0,0>", "advance1": "k_advance<1,1>", "advance2": "k_advance<2,2>", "lap": "k_lap1<1>",
+                "dss": "k_dss_t2<1>", "remap": "k_remap<1>"}
 
 
 def measured_traffic(ne, qsize, n_gpus, group):
@@ -33,8 +38,8 @@ def measured_traffic(ne, qsize, n_gpus, group):
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_ne120_q35.json")))
         c = t["config"]
-        if (c["ne"], c["qsize"], c["n_gpus"]) == (ne, qsize, n_gpus):
-            return t["group_mean_hbm_bytes_per_launch"].get(group)
+        if (c["ne"], c["qsize"], c["n_gpus"]) == (ne, qsize, n_gpus) and os.environ.get("TSE_DSS_ON_READ", "1") != "0":
+            return t["kernels"][KERNEL_NAMES[group]]["hbm_bytes_per_launch"]
     except Exception:  # noqa: BLE001
         pass
     return None
@@ -129,13 +134,13 @@ def main():
         cs = torch.tensor([checksum], dtype=torch.int64, device=dev)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         checksum = int(cs.item())
-    ktimes = {k: run.hip.kernel_time(k) for k in ("advance", "dss", "lap", "minmax", "remap", "level", "dcmip", "avg")}
+    ktimes = {k: run.hip.kernel_time(k) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap", "level", "dcmip", "avg")}
     run.hip.timing(False)
     if rank == 0:
         nelem_total = 6 * a.ne * a.ne
         dof_steps = float(nelem_total) * 16 * 72 * a.qsize * a.steps
         value = dof_steps / elapsed
-        dom = max(KERNEL_BYTES_PER_DOF, key=lambda k: ktimes[k][0])
+        dom = max(KERNEL_BYTES_PER_DOF, key=lambda k: ktimes[k][0])   # the kernel the step spends most time in
         ms, n = ktimes[dom]
         dof_local = float(run.mine.size) * 16 * 72 * a.qsize
         ach = (KERNEL_BYTES_PER_DOF[dom] * dof_local / 1e9) / (ms / max(n, 1) / 1e3) if ms > 0 else 0.0
@@ -147,7 +152,7 @@ def main():
             "config": {"workload": "ne%d DCMIP1-1 prim_run, NP=4, 72L, qsize=%d, rsplit=3, limiter8, nu_q=%g, tstep=%g; "
                                    "%d elements sharded over %d GPU(s)" % (a.ne, a.qsize, run.nu_q, run.tstep, nelem_total, a.gpus),
                        "ne": a.ne, "nlev": 72, "qsize": a.qsize, "elements_per_gpu": int(run.mine.size)},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(a.ne, a.qsize, a.gpus, dom), "avg_ms": ms / max(n, 1), "launches": n,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
                          "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (a.gpus * HBM_PEAK_GBS * 1e9)},

@@ -126,7 +126,7 @@ int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
  * "eta_dot_dpdn", "omega_p", "dp3d", "ps_v", "qmin", "qmax", "sendbuf", "recvbuf" */
 void *tse_device_ptr(tse_ctx *ctx, const char *name, size_t *nbytes);
 /* accumulated HIP-event time (ms) and launch count of a named kernel group since the last reset; names:
- * "advance", "dss", "lap", "minmax", "remap", "level", "dcmip", "avg" */
+ * "advance" (= "advance0" + "advance1" + "advance2", the three RK stages), "dss", "lap", "minmax", "remap", "level", "dcmip", "avg" */
 int tse_kernel_time(tse_ctx *ctx, const char *name, double *ms, long *launches);
 int tse_timing(tse_ctx *ctx, int enable); /* enable/disable + reset per-kernel event timing */
 int tse_halo_layout(tse_ctx *ctx, int *ncol_send, int *ncol_recv);

@@ -290,7 +290,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   const size_t lev = c->lev(), trc = c->trc();
   // scratch fields T, B: one plane per tracer = local elements + one all-zero element (target of empty gather slots) +
   // the received halo columns (DSS-on-read reads them from there); see tse_kernels.h
-  c->tps = (((size_t)(n + 1) * 16 * NLEV + (size_t)std::max(0, c->ncol_recv) * NLEV) + 15) / 16 * 16;
+  c->tps = (((size_t)(n + 1) * 16 * TLEV + (size_t)std::max(0, c->ncol_recv) * NLEV) + 15) / 16 * 16;
   if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps))
     return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
   HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
@@ -544,12 +544,12 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     }
     c->mm_valid = 0;
     if (neighbor_minmax(c)) return 1;
-    Scope s(c, "advance");
+    Scope s(c, "advance0");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
                        c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
     LAUNCH_CHECK();
   } else if (rhs == 1) {
-    Scope s(c, "advance");
+    Scope s(c, "advance1");
     if (gor)   // input: stage 1's scratch T (with its halo columns), output: B
       hipLaunchKernelGGL((k_advance<1, 1>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)c->T,
                          (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
@@ -575,7 +575,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     }
     if (halo_exchange(c, nq)) return 1;
     if (unpack_halo(c, c->T, nq)) return 1;
-    Scope s(c, "advance");
+    Scope s(c, "advance2");
     hipLaunchKernelGGL((k_advance<2, 2>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)Qnp1,
                        (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
                        GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
@@ -615,7 +615,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       LAUNCH_CHECK();
     }
     if (neighbor_minmax(c)) return 1;
-    Scope s(c, "advance");
+    Scope s(c, "advance2");
     if (fused)
       hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
                          c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
@@ -651,7 +651,7 @@ int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) 
   const bool f = fuse_stage3();
   const bool gor = !f && dss_on_read() && c->tps * 8 < ((size_t)1 << 32);   // gather offsets are 32-bit bytes within a plane
   if (gor && c->t_zero_dirty) {   // restore the all-zero element of every plane of T
-    HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * NLEV, c->tps * 8, 0, (size_t)16 * NLEV * 8, c->qsize, c->stream));
+    HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * TLEV, c->tps * 8, 0, (size_t)16 * TLEV * 8, c->qsize, c->stream));
     c->t_zero_dirty = false;
   }
   if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f, true, gor)) return 1;
@@ -762,9 +762,11 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
 int tse_timing(tse_ctx* c, int enable) { resolve_timers(c); c->timing = enable != 0; c->timers.clear(); return 0; }
 int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {
   resolve_timers(c);
-  auto it = c->timers.find(name);
-  if (it == c->timers.end()) { if (ms) *ms = 0; if (launches) *launches = 0; return 0; }
-  if (ms) *ms = it->second.ms; if (launches) *launches = it->second.n;
+  double t = 0; long n = 0;
+  const size_t len = strlen(name);
+  for (auto& kv : c->timers)   // prefix match: "advance" = advance0 + advance1 + advance2
+    if (kv.first.compare(0, len, name) == 0) { t += kv.second.ms; n += kv.second.n; }
+  if (ms) *ms = t; if (launches) *launches = n;
   return 0;
 }
 

@@ -22,6 +22,12 @@ constexpr int SLAB_THREADS = 320;  // k_dss_t: block = element, 72 levels x 4 ro
 // 72-level element is 4.5 waves, so element-sized blocks idle 10% of their lanes and -- worse -- come in units of 5 waves,
 // which leaves SIMD wave slots empty whenever the register budget allows 2 or 3 waves per SIMD (8 or 12 per CU).
 constexpr int FLAT_THREADS = 256;
+// Row pitch (levels) of the scratch layout.  Measured: padding the rows to 80 levels (every [p] row on a 128-B line) is 3 %
+// slower than the dense 72, and a wave mapping that starts every 16-level chunk on a multiple of 16 changes nothing.
+#ifndef TSE_TLEV
+#define TSE_TLEV NLEV
+#endif
+constexpr int TLEV = TSE_TLEV;
 // Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
 // XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[e][q][p][:]
 // rows through the same L2 (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
@@ -31,8 +37,8 @@ struct SlabId { int e, k; bool live; };
 // lines its neighbours are reading at the same moment (L2) instead of going to HBM for the north/south edges.
 __device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ order = nullptr) {
   const int per = gridDim.x >> 3, lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   SlabId s;
+  const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   s.live = gs < n;
   const int g = s.live ? gs : n - 1;   // idle tail lanes recompute the last slab and store nothing
   const int slot = g / NLEV;
@@ -43,7 +49,7 @@ __device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ 
 inline int flat_blocks(int nelemd) { return 8 * ((nelemd * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
 
 // element index of T[q][e][p][k] in the tracer-major scratch layout
-__device__ __forceinline__ size_t t_idx(size_t tps, int q, int e, int p, int k) { return (size_t)q * tps + ((size_t)e * 16 + p) * NLEV + k; }
+__device__ __forceinline__ size_t t_idx(size_t tps, int q, int e, int p, int k) { return (size_t)q * tps + ((size_t)e * 16 + p) * TLEV + k; }
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
@@ -145,16 +151,16 @@ struct RowGather {
 __device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, int nelemd, int e, int j, int k) {
   constexpr int NS = 8;
   const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
-  R.own = (unsigned)(((e * 16 + j * 4) * NLEV + k) * 8);
+  R.own = (unsigned)(((e * 16 + j * 4) * TLEV + k) * 8);
   int2 tt[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) tt[s] = A.tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
 #pragma unroll
   for (int s = 0; s < NS; s++) {
     const int2 t = tt[s];
-    unsigned slot = (unsigned)(nelemd * 16 * NLEV + k);                                    // the zero element
-    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * NLEV + k);
-    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * NLEV + (-(t.x + 2)) * NLEV + k);   // halo column -(t.x+2)
+    unsigned slot = (unsigned)(nelemd * 16 * TLEV + k);                                    // the zero element
+    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * TLEV + k);
+    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * TLEV + (-(t.x + 2)) * NLEV + k);   // halo column -(t.x+2)
     R.go[s] = slot * 8u;
   }
   load4(A.rspheremp + (size_t)e * 16 + j * 4, R.rs);
@@ -168,7 +174,7 @@ __device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, 
                "+v"(R.go[7]));
   const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.tps);   // wave-uniform
 #pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double*>(pq + (R.own + (unsigned)(i * NLEV * 8)));
+  for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double*>(pq + (R.own + (unsigned)(i * TLEV * 8)));
 #pragma unroll
   for (int s = 0; s < 8; s++) a[s] = *reinterpret_cast<const double*>(pq + R.go[s]);
 }
@@ -188,7 +194,7 @@ __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* _
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nq) return;
   const int col = (int)(t / nq), l = (int)(t % nq), q = l / NLEV, k = l - q * NLEV;
-  dst[(size_t)q * tps + (size_t)(nelemd + 1) * 16 * NLEV + (size_t)col * NLEV + k] = recvbuf[(size_t)col * nlyr_halo + l];
+  dst[(size_t)q * tps + (size_t)(nelemd + 1) * 16 * TLEV + (size_t)col * NLEV + k] = recvbuf[(size_t)col * nlyr_halo + l];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
       // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
       double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
 #pragma unroll
-      for (int i = 0; i < 4; i++) tp[(size_t)i * NLEV] = o.x[i];
+      for (int i = 0; i < 4; i++) tp[(size_t)i * TLEV] = o.x[i];
       if (j == 0) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
     }
   };
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
       if (k < NLEV) {
         double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);   // scratch layout, as T
 #pragma unroll
-        for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
+        for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = l1[i];
         if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
       }
     }
@@ -412,7 +418,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
       store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
       double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);
 #pragma unroll
-      for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = o.l[i];
+      for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = o.l[i];
       if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = o.mn; qmax[((size_t)e * qsize + q) * NLEV + k] = o.mx; }
     }
   };
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_t(int nelemd, int qsiz
     const size_t dq = (size_t)(q - q0);
     double v[4], a[NS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = own0[dq * X.tps + (size_t)i * NLEV];
+    for (int i = 0; i < 4; i++) v[i] = own0[dq * X.tps + (size_t)i * TLEV];
 #pragma unroll
     for (int s = 0; s < NS; s++) a[s] = 0.0;
     // loads only (predicated per lane); every use comes after the last load so that no wait lands between them
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_t(int nelemd, int qsiz
       if (k < NLEV) {
         double* bp = X.lapout + t_idx(X.tps, q, e, j * 4, k);
 #pragma unroll
-        for (int i = 0; i < 4; i++) bp[(size_t)i * NLEV] = l1[i];
+        for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = l1[i];
         if (j == 0) { X.qmin[((size_t)e * qsize + q) * NLEV + k] = mn; X.qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
       }
     }
@@ -685,7 +691,7 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
     const size_t dq = (size_t)(q - q0);
     double2 v[4], a[NS];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * tps + (size_t)i * NLEV);
+    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * tps + (size_t)i * TLEV);
 #pragma unroll
     for (int s = 0; s < NS; s++) a[s] = make_double2(0.0, 0.0);
 #pragma unroll
