@@ -141,22 +141,31 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 // have stored.  That removes one read+write pass over the tracers per fused hand-over.
 struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const int* order; };
 // Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
-// per-load address arithmetic, 9 registers).  An empty table slot points into the all-zero element behind the local ones,
-// a remote slot into the halo columns that k_unpack_halo copied behind that, so all 12 loads are unconditional and alike.
+// per-load address arithmetic).  An empty table slot points into the all-zero element behind the local ones, a remote slot
+// into the halo columns that k_unpack_halo copied behind that, so all loads are unconditional and alike.
+// The quad shares the work: a slab needs 20 neighbour values -- 8 for each of the rows j = 0 and 3 (points i = 0 and 3 take
+// up to two edges and a corner, i = 1,2 one edge), 2 for each of the rows j = 1,2 (west and east edge) -- so every lane
+// fetches 5: the middle rows fetch, besides their own two, the third contribution of point 0 and the contributions of points
+// 1 and 2 of the edge row next to them and hand them over with one quad_perm DPP move each.  9 loads per lane and tracer
+// instead of 12, none of them to the zero element for a full interior element, 6 offsets instead of 9.
 struct RowGather {
   unsigned own;      // T[.][e][j*4][k]
-  unsigned go[8];    // the 8 contributions
+  unsigned go[5];    // the lane's five fetches
   double rs[4];
 };
 __device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, int nelemd, int e, int j, int k) {
-  constexpr int NS = 8;
-  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
+  const bool edge = (j == 0) | (j == 3);
+  const int jt = j == 1 ? 0 : (j == 2 ? 3 : j);   // the edge row a middle row helps
+  // (row, point, contribution index) of the five fetches
+  const int rw[5] = {j, j, edge ? j : jt, edge ? j : jt, edge ? j : jt};
+  const int pt[5] = {0, edge ? 0 : 3, edge ? 3 : 0, edge ? 3 : 1, edge ? 3 : 2};
+  const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
   R.own = (unsigned)(((e * 16 + j * 4) * TLEV + k) * 8);
-  int2 tt[NS];
+  int2 tt[5];
 #pragma unroll
-  for (int s = 0; s < NS; s++) tt[s] = A.tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
+  for (int s = 0; s < 5; s++) tt[s] = A.tab[((size_t)e * 16 + rw[s] * 4 + pt[s]) * 3 + cn[s]];
 #pragma unroll
-  for (int s = 0; s < NS; s++) {
+  for (int s = 0; s < 5; s++) {
     const int2 t = tt[s];
     unsigned slot = (unsigned)(nelemd * 16 * TLEV + k);                                    // the zero element
     if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * TLEV + k);
@@ -165,27 +174,30 @@ __device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, 
   }
   load4(A.rspheremp + (size_t)e * 16 + j * 4, R.rs);
 }
-// loads only, all 12 in flight together; every use comes later.
+// loads only, all 9 in flight together; every use comes later.
 // The empty asm keeps the offsets opaque inside the tracer loop: otherwise their zero-extension is hoisted out of the loop
-// (18 registers instead of 9) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
+// (two registers per offset) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
 __device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q,
-                                             double v[4], double a[8]) {
-  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]), "+v"(R.go[3]), "+v"(R.go[4]), "+v"(R.go[5]), "+v"(R.go[6]),
-               "+v"(R.go[7]));
+                                             double v[4], double a[5]) {
+  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]), "+v"(R.go[3]), "+v"(R.go[4]));
   const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.tps);   // wave-uniform
 #pragma unroll
   for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double*>(pq + (R.own + (unsigned)(i * TLEV * 8)));
 #pragma unroll
-  for (int s = 0; s < 8; s++) a[s] = *reinterpret_cast<const double*>(pq + R.go[s]);
+  for (int s = 0; s < 5; s++) a[s] = *reinterpret_cast<const double*>(pq + R.go[s]);
 }
-__device__ __forceinline__ void gather_sum(const RowGather& R, const double v[4], const double a[8], double out[4]) {
-  double t0 = v[0] + a[0]; t0 = t0 + a[1]; t0 = t0 + a[2];
-  double t1 = v[1] + a[3];
-  double t2 = v[2] + a[4];
-  double t3 = v[3] + a[5]; t3 = t3 + a[6]; t3 = t3 + a[7];
+// the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
+__device__ __forceinline__ void gather_sum(const RowGather& R, int j, const double v[4], const double a[5], double out[4]) {
+  const bool edge = (j == 0) | (j == 3);
+  // lanes 0 and 3 receive what lanes 1 and 2 fetched for them: quad_perm [1,1,2,2]
+  const double d2 = dppq<0xA5>(a[2]), d3 = dppq<0xA5>(a[3]), d4 = dppq<0xA5>(a[4]);
+  double t0 = v[0] + a[0]; t0 = t0 + (edge ? a[1] : 0.0); t0 = t0 + (edge ? d2 : 0.0);
+  double t1 = v[1] + (edge ? d3 : 0.0);
+  double t2 = v[2] + (edge ? d4 : 0.0);
+  double t3 = v[3] + (edge ? a[2] : a[1]); t3 = t3 + (edge ? a[3] : 0.0); t3 = t3 + (edge ? a[4] : 0.0);
   out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
   // the sums must be complete before the next tracer's loads are issued into v/a: pin them here (the compiler would
-  // otherwise sink the adds below the loads and keep a second copy of all 12 values)
+  // otherwise sink the adds below the loads and keep a second copy of all the values)
   asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : : "memory");
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
   };
   RowGather RG;
-  double gv[4], ga[8];                                   // raw own/neighbour values of the gathered input (DSS on read)
+  double gv[4], ga[5];                                   // raw own/neighbour values of the gathered input (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
   const double* gsrc = GIN == 1 ? Qn0 : lap;
   auto fetch = [&](int q) {   // loads only
@@ -283,13 +295,13 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   fetch(0);
   auto step = [&](int q, const Out* prev, Out& cur) {
     double qn[4], ls[4] = {0, 0, 0, 0}, minp = minx, maxp = maxx;
-    if (GIN == 1) gather_sum(RG, gv, ga, qn);
+    if (GIN == 1) gather_sum(RG, j, gv, ga, qn);
     else {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
       asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
     }
-    if (RHS == 2 && GIN == 2) gather_sum(RG, gv, ga, ls);
+    if (RHS == 2 && GIN == 2) gather_sum(RG, j, gv, ga, ls);
     else if (RHS >= 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) ls[i] = lsx[i];
@@ -385,7 +397,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 #pragma unroll
   for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   RowGather RG;
-  double gv[4], ga[8];
+  double gv[4], ga[5];
   if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, gv, ga); }
   if (!GIN) {
     for (int q = 0; q < qsize; q++) {
@@ -424,7 +436,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   };
   auto step = [&](int q, const Out* prev, Out& cur) {
     double x[4];
-    gather_sum(RG, gv, ga, x);
+    gather_sum(RG, j, gv, ga, x);
     __builtin_amdgcn_sched_barrier(0);
     if (prev) put(*prev, q - 1);
     gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, gv, ga);   // branch-free: the last step re-reads its own tracer
