@@ -193,10 +193,11 @@ def test_limiter_edge_cases_through_the_step(ctx5):
         assert relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q]) < 20 * TOL_STEP, q
 
 
-def test_many_tracers_qsize_40():
-    """qsize > 36 exercises the tracer-chunk loops (k_remap walks tracers 36 at a time, k_dss_t 5 at a time);
-    BASELINE configs[4] stresses qsize=200."""
-    o = po.Oracle(2, 40, nu_q=1e19)
+@pytest.mark.parametrize("qsize", [40, 200])
+def test_many_tracers(qsize):
+    """qsize > 36 exercises the tracer-chunk loops (k_remap walks tracers 36 at a time, k_dss_t2 5 at a time);
+    200 is BASELINE configs[4]'s stress size."""
+    o = po.Oracle(2, qsize, nu_q=1e19, threads=8)
     elem = elem_from_oracle(o)
     hip = make_hip(o, elem)
     hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()

@@ -75,6 +75,7 @@ struct tse_ctx {
   size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
+  DcmipTab* dcmip_tab = nullptr;   // level-only factors of the prescribed fields
   double* dvv_d = nullptr;   // device copy of Dvv
   GeoPtrs geo() const { return GeoPtrs{Dinv, metdet, rmetdet, spheremp, rspheremp, dvv_d}; }
 };
@@ -323,7 +324,7 @@ void tse_finalize(tse_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
+  void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->lvl_tmp2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -707,6 +708,9 @@ int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, c
   void* old[] = {c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : old) if (p) (void)hipFree(p);
   if (upload(&c->lat, la) || upload(&c->lon, lo) || upload(&c->zm, zm) || upload(&c->zi, zi) || upload(&c->pint, pint) || upload(&c->dph, dph)) return 1;
+  if (!c->dcmip_tab && dalloc(&c->dcmip_tab, 1)) return 1;
+  hipLaunchKernelGGL(k_dcmip_tables, dim3(1), dim3(128), 0, c->stream, test, c->zm, c->zi, c->dcmip_tab);   // level-only factors
+  LAUNCH_CHECK();
   return 0;
 }
 int tse_dcmip_set_initial(tse_ctx* c) {
@@ -722,10 +726,10 @@ int tse_dcmip_set_initial(tse_ctx* c) {
 int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
   if (!c->dcmip_test) return fail("tse_dcmip_step_inputs: call tse_dcmip_init first");
   Scope s(c, "dcmip");
-  size_t tot = (size_t)c->nelemd * NLEVP * 16;
+  size_t tot = (size_t)c->nelemd * 16;   // one thread per column
   double t_wind = (nstep > 0 ? nstep - 1 : 0) * tstep, t_now = nstep * tstep;
   hipLaunchKernelGGL(k_dcmip_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
-                     c->lat, c->lon, c->zm, c->zi, c->pint, c->vn0, c->dp, c->eta, c->omega_p);
+                     c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dp, c->eta, c->omega_p);
   LAUNCH_CHECK();
   return 0;
 }

@@ -1117,25 +1117,92 @@ __device__ inline DcmipPt dcmip_point(int test, double time, double lon, double 
 }
 
 // per-step inputs: derived%dp, vn0 = u(t_wind)*dp, eta_dot_dpdn(t_now), omega_p = 0
-// zm[72], zi[73], pint[73] are per-level constants prepared on the host (dcmip_wrapper_mod.F90:68-89,183)
-__global__ void k_dcmip_step(int nelemd, int test, double t_wind, double t_now, const double* __restrict__ lat,
-                             const double* __restrict__ lon, const double* __restrict__ zm, const double* __restrict__ zi,
-                             const double* __restrict__ pint, double* __restrict__ vn0, double* __restrict__ dp,
-                             double* __restrict__ eta, double* __restrict__ omega_p) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)nelemd * NLEVP * 16) return;
-  const int p = (int)(t & 15), k = (int)((t >> 4) % NLEVP), e = (int)(t / (NLEVP * 16));
-  const double lo = lon[(size_t)e * 16 + p], la = lat[(size_t)e * 16 + p];
-  DcmipPt r = dcmip_point(test, t_now, lo, la, zi[k]);
-  eta[((size_t)e * NLEVP + k) * 16 + p] = -9.80616 * r.rho * r.w;
-  if (k < NLEV) {
-    DcmipPt m = dcmip_point(test, t_wind, lo, la, zm[k]);
-    double dpr = pint[k + 1] - pint[k];
-    size_t o = ((size_t)e * NLEV + k) * 16 + p;
-    dp[o] = dpr;
-    vn0[(((size_t)e * NLEV + k) * 2 + 0) * 16 + p] = m.u * dpr;
-    vn0[(((size_t)e * NLEV + k) * 2 + 1) * 16 + p] = m.v * dpr;
-    omega_p[o] = 0.0;
+// zm[72], zi[73], pint[73] are per-level constants prepared on the host (dcmip_wrapper_mod.F90:68-89,183).
+// The prescribed fields factor into (level-only) x (column-only) x (time-only) terms; evaluating dcmip_point per grid point
+// spends ~15 transcendental calls on every one of the 73 levels of a column.  k_dcmip_tables evaluates the level-only
+// factors once (same device libm, same expression trees as dcmip_point, cut exactly where the left-to-right product order
+// allows it, so the values are identical), k_dcmip_step evaluates the column-only factors once per column and step and
+// then only multiplies.
+struct DcmipTab { double m1[NLEV], m2[NLEV], i1[NLEVP], i2[NLEVP], i3[NLEVP]; };
+__global__ void k_dcmip_tables(int test, const double* __restrict__ zm, const double* __restrict__ zi, DcmipTab* __restrict__ T) {
+  const int k = threadIdx.x;
+  if (k >= NLEVP) return;
+  const double a = 6.376e6, pi = 3.141592653589793238462643383279, Rd = 287.04, g = 9.80616, T0 = 300.0, P0 = 100000.0;
+  const double H = Rd * T0 / g;
+  for (int half = 0; half < 2; half++) {   // 0: interface zi[k], 1: mid level zm[k]
+    if (half == 1 && k >= NLEV) break;
+    const double z = half ? zm[k] : zi[k];
+    const double p = P0 * exp(-z / H);
+    if (test == 1) {
+      const double tau = 12.0 * 86400.0, omega0 = (23000.0 * pi) / tau;
+      const double ptop = P0 * exp(-12000.0 / H), plim = fmax(p, ptop), bs = (double)0.2f;
+      if (half) {
+        T->m1[k] = -exp((plim - P0) / (bs * ptop)) + exp((ptop - plim) / (bs * ptop));   // last factor of ud
+        T->m2[k] = 0.0;
+      } else {
+        T->i1[k] = -((Rd * T0) / (g * plim)) * omega0;                                     // leading factors of w
+        T->i2[k] = 1.0 + exp((ptop - P0) / (bs * ptop)) - exp((plim - P0) / (bs * ptop)) - exp((ptop - plim) / (bs * ptop));   // s
+        T->i3[k] = -9.80616 * (p / (Rd * T0));                                             // -g*rho
+      }
+    } else {
+      const double w0 = 0.15, K = 5.0, ztop = 12000.0;
+      const double ptop = P0 * exp(-ztop / H), rho = fmax(p, ptop) / (Rd * T0), rho0 = P0 / (Rd * T0);
+      const double hstar = fmin(z / ztop, 1.0);
+      if (half) {
+        T->m1[k] = -(rho0 / rho) * (a * w0 * pi) / (K * ztop);   // leading factors of v
+        T->m2[k] = cos(pi * hstar);
+      } else {
+        T->i1[k] = (rho0 / rho) * (w0 / K);                      // leading factors of w
+        T->i2[k] = sin(pi * hstar);
+        T->i3[k] = -9.80616 * rho;
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_dcmip_step(int nelemd, int test, double t_wind, double t_now, const double* __restrict__ lat,
+                                                    const double* __restrict__ lon, const DcmipTab* __restrict__ T,
+                                                    const double* __restrict__ pint, double* __restrict__ vn0, double* __restrict__ dp,
+                                                    double* __restrict__ eta, double* __restrict__ omega_p) {
+  // thread = one column (e,p); the 16 columns of an element are 16 consecutive lanes, so every level is a 128-B store
+  const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= (size_t)nelemd * 16) return;
+  const int p = (int)(col & 15), e = (int)(col >> 4);
+  const double lo = lon[col], la = lat[col];
+  const double a = 6.376e6, pi = 3.141592653589793238462643383279;
+  double u_col, v_col, u_lev = 0.0, w_col, ct_w;   // u = u_col + u_lev*m1 ; v = v_col (test 1) | ((m1*v_col)... (test 2) ; w per test
+  double cl = cos(la);
+  if (test == 1) {
+    const double tau = 12.0 * 86400.0, u0 = (2.0 * pi * a) / tau, k0 = (10.0 * a) / tau, omega0 = (23000.0 * pi) / tau;
+    const double H = 287.04 * 300.0 / 9.80616, ptop = 100000.0 * exp(-12000.0 / H), bs = (double)0.2f;
+    const double lonp = lo - 2.0 * pi * t_wind / tau;
+    u_col = k0 * sin(lonp) * sin(lonp) * sin(2.0 * la) * cos(pi * t_wind / tau) + u0 * cos(la);
+    u_lev = (omega0 * a) / (bs * ptop) * cos(lonp) * (cl * cl) * cos(2.0 * pi * t_wind / tau);
+    v_col = k0 * sin(2.0 * lonp) * cos(la) * cos(pi * t_wind / tau);
+    const double lonw = lo - 2.0 * pi * t_now / tau;
+    w_col = sin(lonw); ct_w = cos(2.0 * pi * t_now / tau);
+  } else {
+    const double tau = 86400.0, u0 = 40.0, K = 5.0;
+    u_col = u0 * cos(la);
+    v_col = sin(K * la); ct_w = cos(pi * t_wind / tau);                 // v = (((m1*cos(lat))*sin(K lat))*m2)*cos(pi t/tau)
+    w_col = -2.0 * sin(K * la) * sin(la) + K * cos(la) * cos(K * la);   // w = ((i1*w_col)*i2)*cos(pi t_now/tau)
+    u_lev = cos(pi * t_now / tau);
+  }
+  for (int k = 0; k < NLEVP; k++) {
+    double w;
+    if (test == 1) w = T->i1[k] * w_col * cl * ct_w * T->i2[k];
+    else w = T->i1[k] * w_col * T->i2[k] * u_lev;
+    eta[((size_t)e * NLEVP + k) * 16 + p] = T->i3[k] * w;
+    if (k < NLEV) {
+      const double dpr = pint[k + 1] - pint[k];
+      double u, v;
+      if (test == 1) { u = u_col + u_lev * T->m1[k]; v = v_col; }
+      else { u = u_col; v = T->m1[k] * cl * v_col * T->m2[k] * ct_w; }
+      const size_t o = ((size_t)e * NLEV + k) * 16 + p;
+      dp[o] = dpr;
+      vn0[(((size_t)e * NLEV + k) * 2 + 0) * 16 + p] = u * dpr;
+      vn0[(((size_t)e * NLEV + k) * 2 + 1) * 16 + p] = v * dpr;
+      omega_p[o] = 0.0;
+    }
   }
 }
 
