@@ -70,7 +70,7 @@ struct tse_ctx {
   struct Pending { const char* name; hipEvent_t a, b; };
   std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
   std::vector<hipEvent_t> free_events;
-  double *lvl_tmp2 = nullptr;
+  double *lvl_tmp2 = nullptr, *eta2 = nullptr;   // twin buffers of the level fields (k_dss_lvl writes out of place, then swap)
   bool t_zero_dirty = false;   // the per-stage stage-3 path used T as a plain [e][q][k][p] field (overwrites its zero elements)
   size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
@@ -297,7 +297,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
-      dalloc(&c->lvl_tmp, lev) || dalloc(&c->lvl_tmp2, lev)) return 1;
+      dalloc(&c->lvl_tmp, lev) || dalloc(&c->lvl_tmp2, lev) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
   const size_t mm = (size_t)n * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
   HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
@@ -326,7 +326,7 @@ void tse_finalize(tse_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
-                  c->lvl_tmp, c->lvl_tmp2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+                  c->lvl_tmp, c->lvl_tmp2, c->eta2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
   resolve_timers(c);
@@ -466,24 +466,20 @@ static int neighbor_minmax(tse_ctx* c) {
 
 // DSS (+ inverse mass matrix) of a tracer-sized field src -> dst, together with the extra level variable
 // (spheremp*var packed behind the tracers: nlyr = qsize*nlev + nlev as edgeAdv_p1, prim_advection_mod.F90:497,911-919)
-static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double* var /* [e][NLEV or NLEVP][16] */, int var_levels,
-                               const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0,
+static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double** varp /* &c->eta, &c->omega_p, &c->divdp_proj or null */,
+                               int var_levels, const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0,
                                bool skip_tracers = false /* DSS on read: the next stage assembles the tracers itself */) {
   const int nq = c->qsize * NLEV;
-  const double* var_src = var;
-  if (var && var_levels != NLEV) {  // eta_dot_dpdn carries nlev+1 levels per element; DSS levels 1:nlev (:835-837)
-    HIPCHK(hipMemcpy2DAsync(c->lvl_tmp, NLEV * 16 * 8, var, (size_t)var_levels * 16 * 8, NLEV * 16 * 8, c->nelemd, hipMemcpyDeviceToDevice, c->stream));
-    var_src = c->lvl_tmp;
-  }
+  const double* var = varp ? *varp : nullptr;
   if (c->ncol_send) {
     size_t tot = (size_t)c->ncol_send * nq;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, src,
-                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, c->tps);
+                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, c->tps, 0);
     LAUNCH_CHECK();
-    if (var) {
+    if (var) {   // eta_dot_dpdn carries nlev+1 levels per element; levels 1:nlev are exchanged (:835-837)
       size_t tv = (size_t)c->ncol_send * NLEV;
-      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var_src,
-                         c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0);
+      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var,
+                         c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0, var_levels);
       LAUNCH_CHECK();
     }
   }
@@ -510,19 +506,16 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
   }
   if (var) {
     Scope s(c, "level");
-    const int nchunk = (NLEV + DSS_LAYERS - 1) / DSS_LAYERS;
-    // out of place (the source must stay intact while neighbours read it): write a scratch level buffer, copy back
-    double* outbuf = c->lvl_tmp2;
-    hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((c->nelemd + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, c->stream, c->nelemd, NLEV, nchunk, c->dss_tab, c->rspheremp, var_src,
-                       outbuf, (const double*)nullptr, c->recvbuf, nq + NLEV, nq, c->spheremp);
+    // out of place into the field's twin buffer (the source must stay intact while neighbours read it), then swap the two
+    double** twin = var_levels == NLEV ? &c->lvl_tmp : &c->eta2;
+    hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
+                       c->rspheremp, c->spheremp, var, var_levels, *twin, var_levels, c->recvbuf, nq + NLEV, nq, c->order);
     LAUNCH_CHECK();
-    if (var_levels == NLEV) HIPCHK(hipMemcpyAsync(var, outbuf, c->lev() * 8, hipMemcpyDeviceToDevice, c->stream));
-    else HIPCHK(hipMemcpy2DAsync(var, (size_t)var_levels * 16 * 8, outbuf, NLEV * 16 * 8, NLEV * 16 * 8, c->nelemd, hipMemcpyDeviceToDevice, c->stream));
+    std::swap(*varp, *twin);
   }
   return 0;
 }
 
-// one RK stage; fuse_avg: apply qdp_time_avg in the final DSS (whole-step path only)
 // gor ("gather on read", whole-step path only): stages 1 and 2 leave their pre-DSS scratch (T, then B) un-DSS'd and the
 // next stage's slab kernel assembles rspheremp*DSS(.) while reading it; the stage-3 Laplacian is handed over the same way.
 static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false,
@@ -531,7 +524,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
   double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
-  double* var = DSSopt == 1 ? c->eta : DSSopt == 2 ? c->omega_p : DSSopt == 3 ? c->divdp_proj : nullptr;
+  double** var = DSSopt == 1 ? &c->eta : DSSopt == 2 ? &c->omega_p : DSSopt == 3 ? &c->divdp_proj : nullptr;
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
   const dim3 grid(flat_blocks(c->nelemd)), blk(FLAT_THREADS);
   if (rhs == 0) {
@@ -571,7 +564,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     if (c->ncol_send) {
       size_t tot = (size_t)c->ncol_send * nq;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->T,
-                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps);
+                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps, 0);
       LAUNCH_CHECK();
     }
     if (halo_exchange(c, nq)) return 1;
@@ -596,7 +589,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       // Laplacian and the bounds as two exchanges of the sizes the halo buffer is dimensioned for
       size_t tot = (size_t)c->ncol_send * nq;
       hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->B,
-                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps);
+                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps, 0);
       LAUNCH_CHECK();
     }
     if (halo_exchange(c, nq)) return 1;

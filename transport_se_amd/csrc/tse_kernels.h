@@ -742,16 +742,63 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
   }
 }
 
+// DSS of one level field (divdp_proj, eta_dot_dpdn(1:nlev), omega_p): dst = rspheremp * DSS(spheremp * src)
+// (prim_advection_mod.F90:911-919,943-957), out of place (the neighbours read src).  src/dst carry src_lev/dst_lev levels per
+// element (eta_dot_dpdn: nlev+1; the extra level is copied through), so no staging copies are needed and the caller just
+// swaps the two buffers.  Lanes flattened over (element slot, level, row) like k_dss_t; all gathers issued before any use.
+__global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const int2* __restrict__ tab, const double* __restrict__ rspheremp,
+                                                              const double* __restrict__ spheremp, const double* __restrict__ src, int src_lev,
+                                                              double* __restrict__ dst, int dst_lev, const double* __restrict__ recvbuf,
+                                                              int nlyr_halo, int lyr0, const int* __restrict__ order) {
+  const DssLane ln = dss_lane<NLEV * 4>(nelemd);
+  if (!ln.live) return;
+  const int e = order[ln.slot], k = ln.r >> 2, j = ln.r & 3;
+  constexpr int NS = 8;
+  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
+  int2 tt[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
+  double v[4], sm[4], rs[4];
+  load4(src + ((size_t)e * src_lev + k) * 16 + j * 4, v);
+  load4(spheremp + (size_t)e * 16 + j * 4, sm);
+  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
+  double a[NS], w[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {   // loads only (predicated per lane); an empty slot contributes +0.0
+    const int2 t = tt[s];
+    a[s] = 0.0; w[s] = 1.0;
+    if (t.x >= 0) { a[s] = src[((size_t)t.x * src_lev + k) * 16 + t.y]; w[s] = spheremp[(size_t)t.x * 16 + t.y]; }
+    else if (t.x <= -2) a[s] = recvbuf[(size_t)(-(t.x + 2)) * nlyr_halo + lyr0 + k];   // packed with the sender's spheremp
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = sm[i] * v[i];
+#pragma unroll
+  for (int s = 0; s < NS; s++) a[s] = tt[s].x >= 0 ? w[s] * a[s] : a[s];
+  v[0] = v[0] + a[0]; v[0] = v[0] + a[1]; v[0] = v[0] + a[2];
+  v[1] = v[1] + a[3];
+  v[2] = v[2] + a[4];
+  v[3] = v[3] + a[5]; v[3] = v[3] + a[6]; v[3] = v[3] + a[7];
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
+  store4(dst + ((size_t)e * dst_lev + k) * 16 + j * 4, v);
+  if (k == NLEV - 1 && src_lev > NLEV && dst_lev > NLEV) {   // the interface below the last level is not DSS'd: copy it
+    double x[4];
+    load4(src + ((size_t)e * src_lev + NLEV) * 16 + j * 4, x);
+    store4(dst + ((size_t)e * dst_lev + NLEV) * 16 + j * 4, x);
+  }
+}
+
 // pack the rank-boundary columns of a [e][nlyr][16] field into sendbuf[col][nlyr_halo] (layer fastest, the
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
-                       size_t tps /* > 0: src is a scratch field (plane stride tps) instead of [e][lyr][p] */) {
+                       size_t tps /* > 0: src is a scratch field (plane stride tps) instead of [e][lyr][p] */,
+                       int src_lyr /* layers per element of a plain src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nlyr) return;
   int col = (int)(t / nlyr), l = (int)(t % nlyr);
   int2 s = send_src[col];
-  double a = tps ? src[t_idx(tps, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * nlyr + l) * 16 + s.y];
+  double a = tps ? src[t_idx(tps, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * src_lyr + l) * 16 + s.y];
   if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
   sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
 }
