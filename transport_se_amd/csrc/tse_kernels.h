@@ -40,7 +40,8 @@ __device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ 
   SlabId s;
   const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   s.live = gs < n;
-  const int g = s.live ? gs : n - 1;   // idle tail lanes recompute the last slab and store nothing
+  const int g = s.live ? gs : n - 2 + (gs & 1);   // idle tail lanes recompute one of the last two slabs (their level parity
+                                                  // is kept: lanes l and l+4 stay a level pair) and store nothing
   const int slot = g / NLEV;
   s.k = g - slot * NLEV;
   s.e = order ? order[slot] : slot;
@@ -143,60 +144,84 @@ struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const 
 // Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
 // per-load address arithmetic).  An empty table slot points into the all-zero element behind the local ones, a remote slot
 // into the halo columns that k_unpack_halo copied behind that, so all loads are unconditional and alike.
-// The quad shares the work: a slab needs 20 neighbour values -- 8 for each of the rows j = 0 and 3 (points i = 0 and 3 take
-// up to two edges and a corner, i = 1,2 one edge), 2 for each of the rows j = 1,2 (west and east edge) -- so every lane
-// fetches 5: the middle rows fetch, besides their own two, the third contribution of point 0 and the contributions of points
-// 1 and 2 of the edge row next to them and hand them over with one quad_perm DPP move each.  9 loads per lane and tracer
-// instead of 12, none of them to the zero element for a full interior element, 6 offsets instead of 9.
+//
+// Who fetches what.  A slab needs its 16 own values and 20 neighbour values -- 8 for each of the rows j = 0 and 3 (points
+// i = 0 and 3 take up to two edges and a corner, i = 1,2 one edge), 2 for each of the rows j = 1,2 (west and east edge).
+//  * The quad shares the neighbour values: every lane is responsible for 5 of the 20 (the middle rows take, besides their own
+//    two, the third contribution of point 0 and the contributions of points 1 and 2 of the edge row next to them) and hands
+//    them over with one quad_perm DPP move each.
+//  * The two lanes that hold the levels (2m, 2m+1) of the same row (lanes l and l+4) share every fetch: the scratch layout
+//    is level-fastest, so one 16-byte load returns both levels.  The even lane loads own points 0,1 and fetches 0,2,4; the
+//    odd lane own points 2,3 and fetches 1,3; the halves are swapped with ds_swizzle (lane ^ 4).
+// That is 5 sixteen-byte loads per lane and tracer (every byte fetched once) instead of 12 eight-byte loads: measured,
+// eight-byte gather loads cost about 1 ms per load instruction and kernel launch even when they hit in L2.
+struct GatherRaw { double2 w[2], g[3]; };
 struct RowGather {
-  unsigned own;      // T[.][e][j*4][k]
-  unsigned go[5];    // the lane's five fetches
+  unsigned own;      // T[.][e][j*4 + (odd ? 2 : 0)][k & ~1]; the second own load is one row (TLEV*8 bytes) further
+  unsigned go[3];    // the lane's three fetches (level pair)
   double rs[4];
 };
+__device__ __forceinline__ double swz_xor4(double x) {   // value of lane ^ 4 (the other level of the pair)
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);   // and 0x1f, or 0, xor 4
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, int nelemd, int e, int j, int k) {
-  const bool edge = (j == 0) | (j == 3);
+  const bool edge = (j == 0) | (j == 3), odd = k & 1;
+  const int kb = k & ~1;
   const int jt = j == 1 ? 0 : (j == 2 ? 3 : j);   // the edge row a middle row helps
-  // (row, point, contribution index) of the five fetches
+  // (row, point, contribution index) of the row's five fetches; this lane loads f = {0,2,4} (even level) or {1,3,3} (odd)
   const int rw[5] = {j, j, edge ? j : jt, edge ? j : jt, edge ? j : jt};
   const int pt[5] = {0, edge ? 0 : 3, edge ? 3 : 0, edge ? 3 : 1, edge ? 3 : 2};
   const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
-  R.own = (unsigned)(((e * 16 + j * 4) * TLEV + k) * 8);
-  int2 tt[5];
+  R.own = (unsigned)(((e * 16 + j * 4 + (odd ? 2 : 0)) * TLEV + kb) * 8);
+  int2 tt[3];
 #pragma unroll
-  for (int s = 0; s < 5; s++) tt[s] = A.tab[((size_t)e * 16 + rw[s] * 4 + pt[s]) * 3 + cn[s]];
+  for (int m = 0; m < 3; m++) {
+    const int se = 2 * m, so = m < 2 ? 2 * m + 1 : 3;
+    const int r = odd ? rw[so] : rw[se], p = odd ? pt[so] : pt[se], c = odd ? cn[so] : cn[se];
+    tt[m] = A.tab[((size_t)e * 16 + r * 4 + p) * 3 + c];
+  }
 #pragma unroll
-  for (int s = 0; s < 5; s++) {
-    const int2 t = tt[s];
-    unsigned slot = (unsigned)(nelemd * 16 * TLEV + k);                                    // the zero element
-    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * TLEV + k);
-    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * TLEV + (-(t.x + 2)) * NLEV + k);   // halo column -(t.x+2)
-    R.go[s] = slot * 8u;
+  for (int m = 0; m < 3; m++) {
+    const int2 t = tt[m];
+    unsigned slot = (unsigned)(nelemd * 16 * TLEV + kb);                                   // the zero element
+    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * TLEV + kb);
+    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * TLEV + (-(t.x + 2)) * NLEV + kb);   // halo column -(t.x+2)
+    R.go[m] = slot * 8u;
   }
   load4(A.rspheremp + (size_t)e * 16 + j * 4, R.rs);
 }
-// loads only, all 9 in flight together; every use comes later.
+// loads only, all 5 in flight together; every use comes later.
 // The empty asm keeps the offsets opaque inside the tracer loop: otherwise their zero-extension is hoisted out of the loop
 // (two registers per offset) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
-__device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q,
-                                             double v[4], double a[5]) {
-  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]), "+v"(R.go[3]), "+v"(R.go[4]));
+__device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q, GatherRaw& raw) {
+  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]));
   const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.tps);   // wave-uniform
+  raw.w[0] = *reinterpret_cast<const double2*>(pq + R.own);
+  raw.w[1] = *reinterpret_cast<const double2*>(pq + (R.own + (unsigned)(TLEV * 8)));
 #pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double*>(pq + (R.own + (unsigned)(i * TLEV * 8)));
-#pragma unroll
-  for (int s = 0; s < 5; s++) a[s] = *reinterpret_cast<const double*>(pq + R.go[s]);
+  for (int m = 0; m < 3; m++) raw.g[m] = *reinterpret_cast<const double2*>(pq + R.go[m]);
 }
 // the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
-__device__ __forceinline__ void gather_sum(const RowGather& R, int j, const double v[4], const double a[5], double out[4]) {
-  const bool edge = (j == 0) | (j == 3);
-  // lanes 0 and 3 receive what lanes 1 and 2 fetched for them: quad_perm [1,1,2,2]
-  const double d2 = dppq<0xA5>(a[2]), d3 = dppq<0xA5>(a[3]), d4 = dppq<0xA5>(a[4]);
-  double t0 = v[0] + a[0]; t0 = t0 + (edge ? a[1] : 0.0); t0 = t0 + (edge ? d2 : 0.0);
-  double t1 = v[1] + (edge ? d3 : 0.0);
-  double t2 = v[2] + (edge ? d4 : 0.0);
-  double t3 = v[3] + (edge ? a[2] : a[1]); t3 = t3 + (edge ? a[3] : 0.0); t3 = t3 + (edge ? a[4] : 0.0);
+__device__ __forceinline__ void gather_sum(const RowGather& R, int j, int k, const GatherRaw& raw, double out[4]) {
+  const bool edge = (j == 0) | (j == 3), odd = k & 1;
+  // level pair exchange: keep my level's half of what I loaded, send the other half to lane ^ 4
+  const double r0 = swz_xor4(odd ? raw.w[0].x : raw.w[0].y), r1 = swz_xor4(odd ? raw.w[1].x : raw.w[1].y);
+  const double v0 = odd ? r0 : raw.w[0].x, v1 = odd ? r1 : raw.w[1].x, v2 = odd ? raw.w[0].y : r0, v3 = odd ? raw.w[1].y : r1;
+  const double s0 = swz_xor4(odd ? raw.g[0].x : raw.g[0].y), s1 = swz_xor4(odd ? raw.g[1].x : raw.g[1].y),
+               s2 = swz_xor4(odd ? raw.g[2].x : raw.g[2].y);
+  // the row's five fetches f0..f4 at this lane's level: even lanes loaded f0,f2,f4, odd lanes f1,f3
+  const double f0 = odd ? s0 : raw.g[0].x, f1 = odd ? raw.g[0].y : s0, f2 = odd ? s1 : raw.g[1].x, f3 = odd ? raw.g[1].y : s1,
+               f4 = odd ? s2 : raw.g[2].x;
+  // quad hand-over: lanes 0 and 3 receive what lanes 1 and 2 fetched for them: quad_perm [1,1,2,2]
+  const double d2 = dppq<0xA5>(f2), d3 = dppq<0xA5>(f3), d4 = dppq<0xA5>(f4);
+  double t0 = v0 + f0; t0 = t0 + (edge ? f1 : 0.0); t0 = t0 + (edge ? d2 : 0.0);
+  double t1 = v1 + (edge ? d3 : 0.0);
+  double t2 = v2 + (edge ? d4 : 0.0);
+  double t3 = v3 + (edge ? f2 : f1); t3 = t3 + (edge ? f3 : 0.0); t3 = t3 + (edge ? f4 : 0.0);
   out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
-  // the sums must be complete before the next tracer's loads are issued into v/a: pin them here (the compiler would
+  // the sums must be complete before the next tracer's loads are issued into `raw`: pin them here (the compiler would
   // otherwise sink the adds below the loads and keep a second copy of all the values)
   asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : : "memory");
 }
@@ -281,12 +306,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
   };
   RowGather RG;
-  double gv[4], ga[5];                                   // raw own/neighbour values of the gathered input (DSS on read)
+  GatherRaw graw;                                        // raw own/neighbour values of the gathered input (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
   const double* gsrc = GIN == 1 ? Qn0 : lap;
   auto fetch = [&](int q) {   // loads only
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = ((size_t)e * qsize + q) * NLEV + kc;
-    if (GIN) gather_issue(RG, GA, gsrc, q, gv, ga);
+    if (GIN) gather_issue(RG, GA, gsrc, q, graw);
     if (GIN != 1) load4(Qn0 + so, qnx);
     if (RHS == 3 || (RHS == 2 && GIN != 2)) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
@@ -295,13 +320,13 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   fetch(0);
   auto step = [&](int q, const Out* prev, Out& cur) {
     double qn[4], ls[4] = {0, 0, 0, 0}, minp = minx, maxp = maxx;
-    if (GIN == 1) gather_sum(RG, j, gv, ga, qn);
+    if (GIN == 1) gather_sum(RG, j, kc, graw, qn);
     else {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
       asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
     }
-    if (RHS == 2 && GIN == 2) gather_sum(RG, j, gv, ga, ls);
+    if (RHS == 2 && GIN == 2) gather_sum(RG, j, kc, graw, ls);
     else if (RHS >= 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) ls[i] = lsx[i];
@@ -397,8 +422,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 #pragma unroll
   for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   RowGather RG;
-  double gv[4], ga[5];
-  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, gv, ga); }
+  GatherRaw graw;
+  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, graw); }
   if (!GIN) {
     for (int q = 0; q < qsize; q++) {
       const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
@@ -436,10 +461,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   };
   auto step = [&](int q, const Out* prev, Out& cur) {
     double x[4];
-    gather_sum(RG, j, gv, ga, x);
+    gather_sum(RG, j, kc, graw, x);
     __builtin_amdgcn_sched_barrier(0);
     if (prev) put(*prev, q - 1);
-    gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, gv, ga);   // branch-free: the last step re-reads its own tracer
+    gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, graw);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 4; i++) { cur.q[i] = x[i]; x[i] = x[i] * dpk[i]; }
