@@ -2,15 +2,12 @@
 TCC_HIT_sum TCC_MISS_sum):   python tools/pmc_traffic.py gpurun_out/<dir> <ne> <qsize> <n_gpus> <out.json>
 
 Corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 FETCH_SIZE reports exactly half of the
-bytes of wide coalesced streaming reads (16 B per lane), so it is doubled for the kernels whose tracer reads are 16-B-per-lane
-loads.  The DSS-on-read kernels and the remap read the tracers with 8-B-per-lane loads, which FETCH_SIZE counts in full
-(checked against k_lap1<1>, whose raw count equals the field it must read), so their factor is 1 (their 16-B level-field
-reads, <= 6 % of the bytes, are then under-counted)."""
+bytes of coalesced reads (128-B requests tallied at 64 B), so it is doubled.  Cross-check kept in the file: TCC_MISS_sum x 128 B
+equals fetch (doubled) + write within a few per cent for every tracer kernel, e.g. k_advance<1,1>: 7.6e8 x 128 B = 97 GB
+vs 63.8 + 34.0 GB -- with the raw FETCH_SIZE the misses would not even cover the field the kernel must read."""
 import csv, glob, json, os, re, sys, collections
 
-FETCH_FACTOR = {"k_advance<0,0>": 2, "k_advance<1,0>": 2, "k_advance<2,0>": 2, "k_advance<3,0>": 2, "k_lap1<0>": 2, "k_dss_t2<0>": 2,
-                "k_dss_t2<1>": 2, "k_dss<0>": 2, "k_divdp": 2, "k_qminmax": 2, "k_advance<1,1>": 1, "k_advance<2,2>": 1, "k_lap1<1>": 1,
-                "k_remap<1>": 1, "k_remap<2>": 1, "k_nbr_minmax": 1, "k_dcmip_step": 1, "k_dcmip_init": 1}
+FETCH_FACTOR = 2
 
 
 def short(n):
@@ -38,7 +35,7 @@ kern = {}
 for k, c in sorted(acc.items()):
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    fac = FETCH_FACTOR.get(k, 1)
+    fac = FETCH_FACTOR
     fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) * 1024 * fac
     write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"]) * 1024
     e = {"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write, "fetch_size_factor": fac,
@@ -46,6 +43,7 @@ for k, c in sorted(acc.items()):
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         h, m = sum(c["TCC_HIT_sum"]), sum(c["TCC_MISS_sum"])
         e["l2_hit_rate"] = h / (h + m) if h + m else None
+        e["tcc_miss_x128B_per_launch"] = m / len(c["TCC_MISS_sum"]) * 128
     kern[k] = e
 json.dump({"config": {"ne": ne, "nlev": 72, "qsize": qsize, "n_gpus": ngpu},
            "command": "tools/pmc_passes.sh: rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 3 --warmup 0 "
