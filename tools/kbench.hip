@@ -1,5 +1,6 @@
-// tools/kbench.hip -- kernel micro-benchmark harness (developer tool, not product): times variants of the slab
-// kernels on ne120-sized synthetic arrays with hipEvents.   hipcc -O3 --offload-arch=gfx950 -o kbench kbench.hip
+// tools/kbench.hip -- kernel micro-benchmark harness (developer tool, not product): times stream/slab copies and the
+// non-gathering slab kernels on ne120-sized synthetic arrays with hipEvents (the DSS-on-read kernels need a real mesh:
+// use bench.py + tools/ab_bench.sh for those).   hipcc -O3 --offload-arch=gfx950 -o kbench kbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -69,63 +70,6 @@ int main(int argc, char** argv) {
   timeit("copy_slab (R+W)", 2 * fb, [&] { hipLaunchKernelGGL(k_copy_slab, dim3(nelem), dim3(SLAB_THREADS), 0, 0, qsize, Q, T); });
   timeit("k_advance<0>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); });
   timeit("k_advance<1>", 2 * fb, [&] { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); });
-  // DSS variants: synthetic regular topology W:e-1 E:e+1 S:e-ne N:e+ne (mod nelem)
-  {
-    std::vector<int2> tab((size_t)nelem * 48, make_int2(-1, 0)), tab0 = tab;
-    auto ep = [](int d, int k) { return d == 0 ? k * 4 : d == 1 ? k * 4 + 3 : d == 2 ? k : 12 + k; };
-    for (int e = 0; e < nelem; e++) {
-      int cnt[16] = {0};
-      int nb[8] = {(e - 1 + nelem) % nelem, (e + 1) % nelem, (e - ne + nelem) % nelem, (e + ne) % nelem,
-                   (e - ne - 1 + nelem) % nelem, (e - ne + 1 + nelem) % nelem, (e + ne - 1) % nelem, (e + ne + 1) % nelem};
-      int eo[4] = {2, 1, 3, 0}, opp[4] = {1, 0, 3, 2};
-      for (int t = 0; t < 4; t++) { int d = eo[t]; for (int k = 0; k < 4; k++) { int p = ep(d, k); tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = make_int2(nb[d], ep(opp[d], k)); } }
-      int cpt[4] = {0, 3, 15, 12}, cd[4] = {4, 5, 7, 6}, cop[4] = {15, 12, 0, 3};
-      for (int t = 0; t < 4; t++) { int p = cpt[t]; tab[((size_t)e * 16 + p) * 3 + cnt[p]++] = make_int2(nb[cd[t]], cop[t]); }
-    }
-    // same table but every source redirected to the element itself (gathers hit L1/L2: isolates issue/TA cost)
-    std::vector<int2> tabs = tab;
-    for (size_t i = 0; i < tabs.size(); i++) if (tabs[i].x >= 0) tabs[i].x = (int)(i / 48);
-    int2* dtabs; CK(hipMalloc(&dtabs, tabs.size() * 8)); CK(hipMemcpy(dtabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
-    int2 *dtab, *dtab0; CK(hipMalloc(&dtab, tab.size() * 8)); CK(hipMalloc(&dtab0, tab.size() * 8));
-    CK(hipMemcpy(dtab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dtab0, tab0.data(), tab.size() * 8, hipMemcpyHostToDevice));
-    double* out; CK(hipMalloc(&out, trc * 8));
-    std::vector<int> ho(nelem); for (int e = 0; e < nelem; e++) ho[e] = e;
-    int* dorder; CK(hipMalloc(&dorder, nelem * 4)); CK(hipMemcpy(dorder, ho.data(), nelem * 4, hipMemcpyHostToDevice));
-    for (int qb : {1, 5, 35}) {
-      int nqc = (qsize + qb - 1) / qb;
-      dim3 grid(8 * dss_blocks_per_xcd<NLEV * 4>(nelem) * nqc);
-      char nm[64];
-      snprintf(nm, 64, "k_dss_t<0> qb=%d nogather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
-      snprintf(nm, 64, "k_dss_t<0> qb=%d selfgather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtabs, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
-      snprintf(nm, 64, "k_dss_t<0> qb=%d gather", qb);
-      timeit(nm, 2 * fb, [&] { hipLaunchKernelGGL(k_dss_t<0>, grid, dim3(DSS_FLAT_THREADS), 0, 0, nelem, qsize, qb, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, DssExtra{}, dorder); });
-    }
-    {   // overlap experiment: VALU-bound advance and memory-bound DSS on two streams, each on half of the tracers' worth of elements
-      hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
-      int nqc = (qsize + 4) / 5;
-      dim3 g2(8 * dss2_blocks_per_xcd(nelem) * nqc);
-      auto adv = [&](hipStream_t st) { hipLaunchKernelGGL(k_advance<1>, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, st, nelem, D, G, qsize, 37.5, 1e13, Q, (const double*)nullptr, T, vn0, dp, divdp, divdp_proj, qmin, qmax, dp0, GatherArgs{nullptr, nullptr, (size_t)(nelem + 1) * 16 * NLEV, nullptr}); };
-      auto dss = [&](hipStream_t st) { hipLaunchKernelGGL(k_dss_t2<0>, g2, dim3(DSS2_THREADS), 0, st, nelem, qsize, 5, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, 0, dorder, (const double*)nullptr, (double*)nullptr, (double*)nullptr); };
-      timeit("k_dss_t2<0> gather", 2 * fb, [&] { dss(0); });
-      timeit("adv<1> then dss (serial)", 4 * fb, [&] { adv(0); dss(0); });
-      // concurrent: note they touch the same T (race is irrelevant for timing)
-      CK(hipDeviceSynchronize());
-      hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
-      for (int rep = 0; rep < 2; rep++) {
-        CK(hipEventRecord(e0, 0)); CK(hipStreamWaitEvent(s1, e0, 0)); CK(hipStreamWaitEvent(s2, e0, 0));
-        for (int r = 0; r < 3; r++) { adv(s1); dss(s2); }
-        CK(hipEventRecord(e1, s1)); CK(hipEventRecord(e2, s2)); CK(hipStreamWaitEvent(0, e1, 0)); CK(hipStreamWaitEvent(0, e2, 0));
-        CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b));
-        float ms; CK(hipEventElapsedTime(&ms, e0, b));
-        if (rep == 1) printf("%-28s %8.3f ms per (adv+dss) pair\n", "adv<1> || dss (2 streams)", ms / 3);
-      }
-    }
-    int nq = qsize * NLEV, nchunk = (nq + DSS_LAYERS - 1) / DSS_LAYERS;
-    timeit("k_dss<0> old gather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });
-    timeit("k_dss<0> old nogather", 2 * fb, [&] { hipLaunchKernelGGL(k_dss<0>, dim3(8 * ((nelem + 7) / 8) * nchunk), dim3(DSS_THREADS), 0, 0, nelem, nq, nchunk, dtab0, m3, T, out, (const double*)nullptr, (const double*)nullptr, nq, 0, (const double*)nullptr); });
-  }
   timeit("k_qminmax", fb, [&] { hipLaunchKernelGGL(k_qminmax, dim3(flat_blocks(nelem)), dim3(FLAT_THREADS), 0, 0, nelem, qsize, 0.0, Q, dp, divdp_proj, qmin, qmax); });
   return 0;
 }

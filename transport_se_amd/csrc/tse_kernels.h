@@ -486,65 +486,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 // Each element adds its neighbours' values in the reference's fixed order (all S, E, N, W, then SW, SE, NE, NW),
 // so results do not depend on how elements are distributed over GPUs.
 //   tab[e][16][3] = {source element (>=0 local, -1 none, <=-2 remote column -(v+2)), source point}
-//   src/dst: [e][nlyr][16]; remote values come from recvbuf[col][nlyr_halo] at layer offset lyr0+l.
-// Block = (element, chunk of 64 layers), thread = (layer, row j).
-constexpr int DSS_THREADS = 256;
-constexpr int DSS_LAYERS = DSS_THREADS / 4;
-template <int MODE>
-__global__ __launch_bounds__(DSS_THREADS) void k_dss(int nelemd, int nlyr, int nchunk, const int2* __restrict__ tab,
-                                                     const double* __restrict__ rspheremp, const double* __restrict__ src,
-                                                     double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                     const double* __restrict__ recvbuf, int nlyr_halo, int lyr0,
-                                                     const double* __restrict__ scale_in /* spheremp or null */) {
-  // work item (chunk, e), chunk-major; the 8 XCDs (blockIdx % 8 shares an XCD, blocks dealt round-robin) each walk a
-  // contiguous range of elements, so that the blocks resident on one XCD at a time cover a compact band of
-  // neighbouring elements of ONE layer chunk and the neighbour-edge gathers hit that XCD's L2
-  const int S8 = (nelemd + 7) >> 3;
-  const int xcd = blockIdx.x & 7, it = blockIdx.x >> 3;
-  const int e = xcd * S8 + it % S8, chunk = it / S8;
-  if (e >= nelemd) return;
-  const int tid = threadIdx.x, j = tid & 3;
-  int l = chunk * DSS_LAYERS + (tid >> 2);
-  const bool active = l < nlyr;
-  if (!active) l = nlyr - 1;
-  __shared__ int2 stab[48];
-  if (tid < 48) stab[tid] = tab[(size_t)e * 48 + tid];
-  __syncthreads();
-  double v[4], rs[4];
-  const size_t off = ((size_t)e * nlyr + l) * 16 + j * 4;
-  load4(src + off, v);
-  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
-  if (scale_in) {
-    double sm[4];
-    load4(scale_in + (size_t)e * 16 + j * 4, sm);
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = sm[i] * v[i];
-  }
-#pragma unroll
-  for (int cidx = 0; cidx < 3; cidx++) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int2 s = stab[(j * 4 + i) * 3 + cidx];
-      if (s.x >= 0) {
-        double a = src[((size_t)s.x * nlyr + l) * 16 + s.y];
-        if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
-        v[i] = v[i] + a;
-      } else if (s.x <= -2) {
-        v[i] = v[i] + recvbuf[(size_t)(-(s.x + 2)) * nlyr_halo + lyr0 + l];
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
-  if (MODE == 1) {
-    double q0[4];
-    load4(Qn0 + off, q0);
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = (q0[i] + 2 * v[i]) / 3;  // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
-  }
-  if (active) store4(dst + off, v);
-}
-
+//   remote values come from recvbuf[col][nlyr_halo] (layer = q*NLEV+k, the reference's message layout).
 // Tracer-field DSS: source in the level-fastest scratch layout src[q][e][p][k] written by k_advance/k_lap1, destination in the
 // standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
 // k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
