@@ -185,15 +185,17 @@ __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L
 #ifdef TSE_LIMITER_STATS
 __device__ unsigned long long g_lim_hist[20];  // [it] slabs converged at iteration it (16 = never), [17] wave-iterations, [18] waves
 #endif
-__device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], double sumc, double& minp, double& maxp) {
+// returns true when the bounds were relaxed (the only case in which minp/maxp change)
+__device__ __forceinline__ bool limiter8_quad(double x[4], const double c[4], double sumc, double& minp, double& maxp) {
   const double tol_limiter = (double)5e-14f;
 #ifdef TSE_LIMITER_STATS
   int my_it = 16, wave_it = 0;
 #endif
-  if (!(sumc > 0.0)) return;  // whole quad takes the same branch
+  if (!(sumc > 0.0)) return false;  // whole quad takes the same branch
   double mass = quad_sum(((c[0] * x[0] + c[1] * x[1]) + c[2] * x[2]) + c[3] * x[3]);
-  if (mass < minp * sumc) minp = mass / sumc;
-  if (mass > maxp * sumc) maxp = mass / sumc;
+  const bool lo = mass < minp * sumc, hi = mass > maxp * sumc;
+  if (lo) minp = mass / sumc;
+  if (hi) maxp = mass / sumc;
   const double tol_mass = tol_limiter * fabs(mass);
   for (int iter = 1; iter <= NP * NP - 1; iter++) {
     // clip to [minp,maxp]; the removed mass is sum (x - clipped)*c: (x-maxp)*c above, -(minp-x)*c below, +0 inside --
@@ -236,6 +238,7 @@ __device__ __forceinline__ void limiter8_quad(double x[4], const double c[4], do
   if ((threadIdx.x & 3) == 0) atomicAdd(&g_lim_hist[my_it], 1ull);
   if ((threadIdx.x & 63) == 0) { atomicAdd(&g_lim_hist[17], (unsigned long long)wave_it); atomicAdd(&g_lim_hist[18], 1ull); }
 #endif
+  return lo | hi;
 }
 
 }  // namespace tse

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   //   wait for this tracer's inputs -> issue the PREVIOUS tracer's stores -> issue the NEXT tracer's loads -> compute.
   // With DB the results go to a second register set (A/B alternate): the stores issued at the top of a step then have the
   // whole step to drain and nothing waits for them (worth its 12 registers where few waves fit: the DSS-on-read kernels).
-  struct Out { double x[4], mn, mx; };
+  struct Out { double x[4], mn, mx; bool ch; };   // ch: the bounds differ from what qmin/qmax already hold
   auto put = [&](const Out& o, int q) {
     if (k < NLEV) {
       // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
       double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
 #pragma unroll
       for (int i = 0; i < 4; i++) tp[(size_t)i * TLEV] = o.x[i];
-      if (j == 0) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
+      if (j == 0 && o.ch) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
     }
   };
   RowGather RG;
@@ -365,10 +365,13 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
+    bool changed = false;
     if (RHS == 1) {
       double q0 = qn[0] * rdpk[0], q1 = qn[1] * rdpk[1], q2 = qn[2] * rdpk[2], q3 = qn[3] * rdpk[3];
-      minp = fmin(minp, quad_min(fmin(fmin(q0, q1), fmin(q2, q3))));
-      maxp = fmax(maxp, quad_max(fmax(fmax(q0, q1), fmax(q2, q3))));
+      const double lmn = quad_min(fmin(fmin(q0, q1), fmin(q2, q3))), lmx = quad_max(fmax(fmax(q0, q1), fmax(q2, q3)));
+      changed = (lmn < minp) | (lmx > maxp);
+      minp = fmin(minp, lmn);
+      maxp = fmax(maxp, lmx);
     }
     if (RHS == 2) {
 #pragma unroll
@@ -380,10 +383,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
-    limiter8_quad(x, c, sumc, minp, maxp);
+    changed |= limiter8_quad(x, c, sumc, minp, maxp);
 #pragma unroll
     for (int i = 0; i < 4; i++) cur.x[i] = c[i] * x[i];   // spheremp * (x*dp_star)
-    cur.mn = minp; cur.mx = maxp;
+    cur.mn = minp; cur.mx = maxp; cur.ch = changed;   // unchanged bounds are not written back (3.5 GB per launch)
   };
   Out A, B;
   if (DB) {
