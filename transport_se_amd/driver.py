@@ -34,6 +34,7 @@ class HaloExchange:
         self.sched, self.dist, self.torch, self.device = sched, dist_mod, torch_mod, device
         self.stage = stage_through_host
         self.len_s = {0: [int(s[2]) for s in sched["send"]]}; self.len_r = {0: [int(s[2]) for s in sched["recv"]]}
+        self._plans = {}
 
     def set_minmax_layout(self, send_len, recv_len):
         """per-slot entry counts of the compact neighbour min/max exchange (kind 1), from tse_halo_minmax_layout"""
@@ -48,29 +49,42 @@ class HaloExchange:
         holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
         return self.torch.as_tensor(holder, device=self.device)
 
+    def _plan(self, sbuf, rbuf, nlyr, kind):
+        """tensor views of the slots and the P2POp list of one (buffers, nlyr, kind) exchange, built once: the library's
+        halo buffers never move, and six exchanges per tracer step make the per-call Python work visible at 8 GPUs"""
+        key = (int(sbuf), int(rbuf), int(nlyr), int(kind))
+        plan = self._plans.get(key)
+        if plan is None:
+            dist = self.dist
+            ls, lr = self.len_s[kind], self.len_r[kind]
+            off_s = np.concatenate([[0], np.cumsum(ls)]).astype(int); off_r = np.concatenate([[0], np.cumsum(lr)]).astype(int)
+            ns, nr = int(off_s[-1]), int(off_r[-1])
+            st = self._wrap(sbuf, ns * nlyr); rt_dev = self._wrap(rbuf, nr * nlyr)
+            staged = self.stage and str(self.device) != "cpu"
+            rt = self.torch.empty(nr * nlyr, dtype=self.torch.float64) if staged else rt_dev
+            st_host = self.torch.empty(ns * nlyr, dtype=self.torch.float64) if staged else None
+            src = st_host if staged else st
+            ops = []
+            for i, (peer, _, _) in enumerate(self.sched["recv"]):
+                if lr[i]:
+                    ops.append(dist.P2POp(dist.irecv, rt[off_r[i] * nlyr:(off_r[i] + lr[i]) * nlyr], int(peer)))
+            for i, (peer, _, _) in enumerate(self.sched["send"]):
+                if ls[i]:
+                    ops.append(dist.P2POp(dist.isend, src[off_s[i] * nlyr:(off_s[i] + ls[i]) * nlyr], int(peer)))
+            plan = self._plans[key] = (ops, st, st_host, rt, rt_dev if staged else None)
+        return plan
+
     def __call__(self, sbuf, rbuf, nlyr, kind=0):
-        torch, dist = self.torch, self.dist
-        ls, lr = self.len_s[kind], self.len_r[kind]
-        off_s = np.concatenate([[0], np.cumsum(ls)]).astype(int); off_r = np.concatenate([[0], np.cumsum(lr)]).astype(int)
-        ns, nr = int(off_s[-1]), int(off_r[-1])
-        st = self._wrap(sbuf, ns * nlyr); rt = self._wrap(rbuf, nr * nlyr)
-        rt_dev = None
-        if self.stage and str(self.device) != "cpu":
-            rt_dev = rt
-            st = st.cpu(); rt = torch.empty(nr * nlyr, dtype=torch.float64)
-        ops = []
-        for i, (peer, _, _) in enumerate(self.sched["recv"]):
-            if lr[i]:
-                ops.append(dist.P2POp(dist.irecv, rt[off_r[i] * nlyr:(off_r[i] + lr[i]) * nlyr], int(peer)))
-        for i, (peer, _, _) in enumerate(self.sched["send"]):
-            if ls[i]:
-                ops.append(dist.P2POp(dist.isend, st[off_s[i] * nlyr:(off_s[i] + ls[i]) * nlyr], int(peer)))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        ops, st, st_host, rt, rt_dev = self._plan(sbuf, rbuf, nlyr, kind)
+        if st_host is not None:
+            st_host.copy_(st)
+        if ops:
+            for req in self.dist.batch_isend_irecv(ops):
+                req.wait()
         if rt_dev is not None:
             rt_dev.copy_(rt)
         if str(self.device) != "cpu":
-            torch.cuda.current_stream(self.device).synchronize()
+            self.torch.cuda.current_stream(self.device).synchronize()
         return 0
 
 
