@@ -43,3 +43,35 @@ def test_ne8_norms_match_reference(name):
     np.testing.assert_allclose(mass1, mass0, rtol=1e-11)
     np.testing.assert_allclose(mass1, ref["mass1"], rtol=1e-10)
     run.close()
+
+
+# README:128-129 "Updated 2015-11-27 (rsplit=3, ACME 72 level config, skybridge)": run_ne30_tests.sh = ne30, tstep 300, nu_q 1e15,
+# qsize 4, DCMIP 1-1 for 12 days and DCMIP 1-2 for 1 day.  Published by the reference's authors on another machine/compiler:
+# a second, independent pin at BASELINE configs[1]'s resolution; all printed digits are reproduced
+# (profiles/r01_ne30_q4_dcmip1-*_prim_main.txt).
+README_NE30 = {"dcmip1-1": dict(L1=0.490013, L2=0.789052, Linf=0.918454, q_max=0.445141, test=1, tracer=1, nsteps=3456),
+               "dcmip1-2": dict(L1=0.121783, L2=0.361005, Linf=1.092784, q_max=0.836177, test=2, tracer=2, nsteps=288)}
+
+
+@pytest.mark.parametrize("name", ["dcmip1-1", "dcmip1-2"])
+def test_ne30_norms_match_readme(name):
+    ref = README_NE30[name]
+    run = PrimRun(30, 4, test_case=ref["test"], nu_q=1e15, tstep=300.0)
+    q0 = run.fetch_qdp(1).copy()
+    from transport_se_amd import cube_mesh as cm
+    geo = cm.geometry(30)
+    mass0 = norms.tracer_mass(geo["spheremp"], q0)
+    np1 = run.run(ref["nsteps"])
+    q1 = run.fetch_qdp(np1)
+    ps_v = run.hip.fetch("ps_v", (run.nelem, 4, 4))
+    tr = ref["tracer"] - 1
+    hv = run.hv
+    got = norms.dcmip_norms_from_qdp(30, run.lat, run.lon, q0[:, tr], q1[:, tr], ps_v, hv.hyai, hv.hybi, hv.hyam, hv.hybm)
+    for k in ("L1", "L2", "Linf", "q_max"):
+        assert abs(got[k] - ref[k]) <= 1.5e-6, (k, got[k], ref[k])   # the README's 6 printed digits (north_star: 3 significant figures)
+    # mass of the evaluated tracer.  (The 0/1 checkerboard tracers of DCMIP 1-2 gain 1.5e-4 of their mass in the first steps at
+    # this resolution in the reference's algorithm itself -- the oracle, bit-exact with the reference, shows the same number --
+    # so they are not part of this check.)
+    mass1 = norms.tracer_mass(geo["spheremp"], q1)
+    assert abs(mass1[tr] - mass0[tr]) <= 1e-11 * abs(mass0[tr])
+    run.close()
