@@ -75,3 +75,26 @@ def test_ne30_norms_match_readme(name):
     mass1 = norms.tracer_mass(geo["spheremp"], q1)
     assert abs(mass1[tr] - mass0[tr]) <= 1e-11 * abs(mass0[tr])
     run.close()
+
+
+# README:149-151 "Updated 2015-11-27 (rsplit=3, ACME 72 level config)": run_ne120_tests.sh = ne120, tstep 75, nu_q 1e13, qsize 4.
+# 12 model days take 6 minutes on one MI355X, so this one only runs on request; its recorded output is
+# profiles/r01_ne120_q4_dcmip1-*_prim_main.txt (all printed digits of both lines, q_min included, are reproduced).
+README_NE120 = {"dcmip1-1": dict(L1=0.479398, L2=0.782613, Linf=0.922696, q_max=0.501561, test=1, tracer=1, nsteps=13824),
+                "dcmip1-2": dict(L1=0.081287, L2=0.264887, Linf=0.591157, q_max=0.959530, test=2, tracer=2, nsteps=1152)}
+
+
+@pytest.mark.skipif(os.environ.get("TSE_LONG_TESTS") != "1", reason="6 GPU-minutes: set TSE_LONG_TESTS=1")
+@pytest.mark.parametrize("name", ["dcmip1-2", "dcmip1-1"])
+def test_ne120_norms_match_readme(name):
+    ref = README_NE120[name]
+    run = PrimRun(120, 4, test_case=ref["test"], nu_q=1e13, tstep=75.0)
+    q0 = run.fetch_qdp(1)[:, ref["tracer"] - 1].copy()
+    np1 = run.run(ref["nsteps"])
+    q1 = run.fetch_qdp(np1)[:, ref["tracer"] - 1]
+    ps_v = run.hip.fetch("ps_v", (run.nelem, 4, 4))
+    hv = run.hv
+    got = norms.dcmip_norms_from_qdp(120, run.lat, run.lon, q0, q1, ps_v, hv.hyai, hv.hybi, hv.hyam, hv.hybm)
+    for k in ("L1", "L2", "Linf", "q_max"):
+        assert abs(got[k] - ref[k]) <= 1.5e-6, (k, got[k], ref[k])
+    run.close()
