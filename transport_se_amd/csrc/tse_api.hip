@@ -70,6 +70,7 @@ struct tse_ctx {
   struct Pending { const char* name; hipEvent_t a, b; };
   std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
   std::vector<hipEvent_t> free_events;
+  double *sink = nullptr;   // write-only dump of the remap's surplus tracer slots (18 x 72 doubles used)
   double *eta2 = nullptr;   // with lvl_tmp: twin buffers of the level fields (k_dss_lvl writes out of place, then swap)
   bool t_zero_dirty = false;   // the per-stage stage-3 path used T as a plain [e][q][k][p] field (overwrites its zero elements)
   size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
@@ -297,7 +298,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
-      dalloc(&c->lvl_tmp, lev) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
+      dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 32) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
   const size_t mm = (size_t)n * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
   HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
@@ -326,7 +327,7 @@ void tse_finalize(tse_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
-                  c->lvl_tmp, c->eta2, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+                  c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
   resolve_timers(c);
@@ -665,10 +666,10 @@ int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
     double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
     if (nt == 1)
       hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic);
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
     else
       hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic);
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
     LAUNCH_CHECK();
   }
   int bad = 0;

@@ -13,6 +13,7 @@
 // looping over the tracers so that everything that depends on (e,k) only -- Vstar, dp, dp_star, the metric rows --
 // is computed once and stays in registers for all qsize tracers.
 #pragma once
+#include <type_traits>
 #include "tse_device.h"
 
 namespace tse {
@@ -911,17 +912,23 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
 // generic loop.
 template <int NT>
 __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
-                                                   double* __restrict__ mn_out, double* __restrict__ mx_out) {
+                                                   double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink) {
   const int p = tid & 15;
   for (int q0 = (tid >> 4) * NT; q0 < qsize; q0 += (nthreads >> 4) * NT) {
+    // The level body below is free of branches and predicated stores, so that the 8 levels of an unrolled block form one
+    // basic block and the scheduler can overlap the dependency chains of neighbouring levels (the kernel waits for memory 9 %
+    // of its time; it is bound by instruction latency at 2.25 waves per SIMD).  A surplus tracer slot (q >= qsize) therefore
+    // reads the last tracer and writes into `sink`; the element min/max is stored by all 16 lanes of the row (same value).
     double* col[NT];
-    bool on[NT];
-    int qq[NT];
+    double *colw[NT], *mnp[NT], *mxp[NT];
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      on[t] = q0 + t < qsize;
-      qq[t] = on[t] ? q0 + t : qsize - 1;   // a surplus slot recomputes the last tracer and stores nothing
-      col[t] = Q + ((size_t)e * qsize + qq[t]) * NLEV * 16 + p;
+      const bool on = q0 + t < qsize;
+      const int qq = on ? q0 + t : qsize - 1;
+      col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
+      colw[t] = on ? col[t] : sink + p;
+      mnp[t] = on && mn_out ? mn_out + ((size_t)e * qsize + qq) * NLEV : sink + NLEV * 16;
+      mxp[t] = on && mn_out ? mx_out + ((size_t)e * qsize + qq) * NLEV : sink + NLEV * 17;
     }
     double pf[NT][REMAP_PF];
     double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
@@ -945,61 +952,83 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
         masso[t] = 0.0; massn1[t] = 0.0;
       }
     }
-    for (int kb = 0; kb < NLEV; kb += REMAP_PF) {
-#pragma unroll
-      for (int sl = 0; sl < REMAP_PF; sl++) {
-        const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
-        double ak3[NT], mk3[NT];
-        if (r <= NLEV) {
-          const double rr = S.rdpo[r + 1][p];
-#pragma unroll
-          for (int t = 0; t < NT; t++) {
-            mk3[t] = pf[t][sl];
-            if (r + REMAP_PF <= NLEV) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
-            ak3[t] = mk3[t] * rr;
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < NT; t++) {   // a(nlev+1) = a(nlev), a(nlev+2) = a(nlev-1); nothing beyond is used
-            mk3[t] = 0.0;
-            ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
-          }
-        }
-        const int jd = k + 2 <= NLEV + 1 ? k + 2 : NLEV + 1, ja = k + 1 <= NLEV ? k + 1 : NLEV;   // last level: results unused
-        const double d0 = S.ppmdx[jd][0][p], d1 = S.ppmdx[jd][1][p], d2 = S.ppmdx[jd][2][p];
-        const double e3 = S.ppmdx[ja][3][p], e4 = S.ppmdx[ja][4][p], e5 = S.ppmdx[ja][5][p], e6 = S.ppmdx[ja][6][p],
-                     e7 = S.ppmdx[ja][7][p], e8 = S.ppmdx[ja][8][p], e9 = S.ppmdx[ja][9][p];
-        const int kt = S.kid[k - 1][p];
-        const bool o = kt != k;   // kid(k) == k+1
-        const double x1 = -0.5, x2 = S.z2[k - 1][p], dsel = S.dpo[kt + 1][p], dn = S.dpn[k - 1][p];
-        const double z1 = x2 - x1, zz2 = (x2 * x2 - x1 * x1) * 0.5, z3 = x2 * x2 * x2 - x1 * x1 * x1;
+    // one level; TAIL: the last two blocks of 8, where the window runs into the mirrored ghost cells and the FIFO runs dry
+    const double *bp, *brdpo, *bdpo, *bz2, *bdpn; const int* bkid;   // per-block LDS bases
+    auto bases = [&](int kb) __attribute__((always_inline)) {
+      bp = &S.ppmdx[kb][0][p]; brdpo = &S.rdpo[kb][p]; bdpo = &S.dpo[kb][p]; bz2 = &S.z2[kb][p]; bdpn = &S.dpn[kb][p]; bkid = &S.kid[kb][p];
+    };
+    auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl) __attribute__((always_inline)) {
+      constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value;
+      const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
+      double ak3[NT], mk3[NT];
+      if (!TAIL || r <= NLEV) {
+        const double rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1]
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-          const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
-          const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e5 * (e6 - e7) * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
-          const double mo1 = masso[t] + mk[t];
-          const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
-          double c0, c1, c2;
-          remap_coefs(al, ar, a0, c0, c1, c2);
-          const double integ = c0 * z1 + c1 * zz2 + c2 * z3 * (1.0 / 3.0);
-          const double massn2 = ms + integ * dsel;
-          const double qnew = massn2 - massn1[t];
-          if (on[t]) col[t][(size_t)(k - 1) * 16] = qnew;
-          massn1[t] = massn2;
-          if (mn_out) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-            const double x = qnew / dn;
-            double mn = x, mx = x;
-            mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
-            mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-            if (p == 0 && on[t]) { mn_out[((size_t)e * qsize + qq[t]) * NLEV + k - 1] = mn; mx_out[((size_t)e * qsize + qq[t]) * NLEV + k - 1] = mx; }
-          }
-          masso[t] = mo1;
-          ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
-          mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
-          dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
+          mk3[t] = pf[t][sl];
+          if (!TAIL || r + REMAP_PF <= NLEV) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
+          ak3[t] = mk3[t] * rr;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {   // a(nlev+1) = a(nlev), a(nlev+2) = a(nlev-1); nothing beyond is used
+          mk3[t] = 0.0;
+          ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
         }
       }
-    }
+      // LDS reads relative to per-block bases (bp = &ppmdx[kb][0][p] etc., set up once per 8 levels): the offsets are then
+      // small compile-time immediates.  Indexed from the struct base, most of the 147 KB lie beyond the 64 KB an LDS
+      // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
+      const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
+      const double d0 = bp[(jdo * 10 + 0) * 16], d1 = bp[(jdo * 10 + 1) * 16], d2 = bp[(jdo * 10 + 2) * 16];
+      const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e5 = bp[(jao * 10 + 5) * 16], e6 = bp[(jao * 10 + 6) * 16],
+                   e7 = bp[(jao * 10 + 7) * 16], e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
+      const int kt = bkid[sl * 16];
+      const bool o = kt != k;   // kid(k) == k+1
+      const double x1 = -0.5, x2 = bz2[sl * 16], dsel = o ? bdpo[(sl + 3) * 16] : bdpo[(sl + 2) * 16], dn = bdpn[sl * 16];
+      const double z1 = x2 - x1, zz2 = (x2 * x2 - x1 * x1) * 0.5, z3 = x2 * x2 * x2 - x1 * x1 * x1;
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
+        const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e5 * (e6 - e7) * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
+        const double mo1 = masso[t] + mk[t];
+        const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
+        double c0, c1, c2;
+        remap_coefs(al, ar, a0, c0, c1, c2);
+        const double integ = c0 * z1 + c1 * zz2 + c2 * z3 * (1.0 / 3.0);
+        const double massn2 = ms + integ * dsel;
+        const double qnew = massn2 - massn1[t];
+        colw[t][(size_t)(k - 1) * 16] = qnew;
+        massn1[t] = massn2;
+        if (EMIT) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
+          const double x = qnew / dn;
+          double mn = x, mx = x;
+          mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
+          mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
+          mnp[t][k - 1] = mn; mxp[t][k - 1] = mx;   // every lane of the row holds the row's result
+        }
+        masso[t] = mo1;
+        ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
+        mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
+        dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
+      }
+    };
+    auto column = [&](auto emit_tag) __attribute__((always_inline)) {
+      constexpr int CLEAN = NLEV - 2 * REMAP_PF;   // blocks starting below this never see a ghost cell or an empty FIFO slot
+      // scheduler fence every 4 levels: an unfenced block of 8 overlaps so much that 35 registers spill (168 is the cap at 9 waves)
+      for (int kb = 0; kb < CLEAN; kb += REMAP_PF) {
+        bases(kb);
+#pragma unroll
+        for (int sl = 0; sl < REMAP_PF; sl++) { level(std::false_type{}, emit_tag, kb, sl); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+      }
+      for (int kb = CLEAN; kb < NLEV; kb += REMAP_PF) {
+        bases(kb);
+#pragma unroll
+        for (int sl = 0; sl < REMAP_PF; sl++) { level(std::true_type{}, emit_tag, kb, sl); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+      }
+    };
+    if (mn_out) column(std::true_type{});
+    else column(std::false_type{});
   }
 }
 
@@ -1009,7 +1038,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
                                                          const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
                                                          double* __restrict__ ps_v, double* __restrict__ Q,
                                                          int* __restrict__ bad, double* __restrict__ mn_out,
-                                                         double* __restrict__ mx_out, int force_generic) {
+                                                         double* __restrict__ mx_out, int force_generic, double* __restrict__ sink) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
   const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
@@ -1079,7 +1108,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
   __syncthreads();
   // ---- phase 2: data part
   if (S.slow) remap_columns_generic(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
-  else remap_columns_fast<NT>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
+  else remap_columns_fast<NT>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink);
 }
 
 // ---------------------------------------------------------------------------------------------------
