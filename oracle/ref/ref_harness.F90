@@ -50,7 +50,7 @@ program ref_harness
 #ifdef TSE_HIP
   ! built by transport_se_amd/fortran/Makefile: prim_advection_mod is the reference's file compiled with
   ! -DUSE_CUDA_FORTRAN=1, and `cuda_mod` is transport_se_amd/fortran/cuda_mod_hip.F90 (the HIP library's Fortran seam)
-  use cuda_mod,           only : cuda_mod_init, copy_qdp_h2d, copy_qdp_d2h
+  use cuda_mod,           only : cuda_mod_init, copy_qdp_h2d, copy_qdp_d2h, advec_tracers_remap_rk2_hip
 #endif
   implicit none
 #include <mpif.h>
@@ -246,6 +246,7 @@ contains
   ! prim_step (prim_driver_mod.F90:856-943) + prim_advance_exp (prim_advance_mod.F90:62-152), ur_weights(1)=1
   subroutine my_prim_step()
     integer :: ie, k
+    character(len=8) :: whole_step_env
     do ie = 1, nelemd
        elem(ie)%derived%eta_dot_dpdn = 0
        elem(ie)%derived%vn0 = 0
@@ -262,6 +263,16 @@ contains
                1.0d0*elem(ie)%state%v(:,:,2,k,tl%n0)*elem(ie)%derived%dp(:,:,k)
        enddo
     enddo
+#ifdef TSE_HIP
+    ! TSE_HARNESS_WHOLE_STEP=1: the one-call entry a maintainer would hook into Prim_Advec_Tracers_remap_rk2 (INTEGRATION.md)
+    ! instead of the reference's per-stage hooks
+    call get_environment_variable('TSE_HARNESS_WHOLE_STEP', whole_step_env)
+    if (trim(whole_step_env) == '1') then
+       call TimeLevel_Qdp(tl, qsplit, n0_qdp, np1_qdp)
+       call advec_tracers_remap_rk2_hip(elem, dt*qsplit, n0_qdp, np1_qdp)
+       return
+    endif
+#endif
     call Prim_Advec_Tracers_remap(elem, deriv(0), hvcoord, flt, hybrid, dt*qsplit, tl, 1, nelemd)
   end subroutine my_prim_step
 

@@ -22,14 +22,22 @@ HARNESS = os.path.join(ROOT, "transport_se_amd", "fortran", "_build", "hip_harne
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
+def _env(whole_step):
+    """whole_step: the harness calls cuda_mod_hip's one-call entry advec_tracers_remap_rk2_hip (the hook a maintainer adds to
+    Prim_Advec_Tracers_remap_rk2) instead of going through the reference's per-stage hooks"""
+    return dict(os.environ, TSE_HARNESS_WHOLE_STEP="1" if whole_step else "0")
+
+
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(MPIEXEC)), reason="Fortran drop-in harness not built")
-def test_reference_hooks_drive_the_hip_library(gold):
+@pytest.mark.parametrize("whole_step", [False, True])
+def test_reference_hooks_drive_the_hip_library(gold, whole_step):
     g = gold("ref_ne2_dcmip11.npz")
     cfg = json.loads(str(g["config"]))
     out = tempfile.mkdtemp(prefix="tse_f90_")
     stdin = "%d %d %d %r %r %d 1\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
                                                  out, os.path.join(ROOT, "tests", "golden", "vcoord"))
-    res = subprocess.run([MPIEXEC, "-n", "1", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    res = subprocess.run([MPIEXEC, "-n", "1", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                         env=_env(whole_step))
     log = res.stdout.decode()
     assert "ref_harness done" in log, log[-2000:]
     for tag, key in (("000001", "qdp_step1"), ("000003", "qdp_step3"), ("000006", "qdp_step6")):
@@ -42,8 +50,8 @@ def test_reference_hooks_drive_the_hip_library(gold):
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(MPIEXEC)), reason="Fortran drop-in harness not built")
-@pytest.mark.parametrize("nranks", [2, 3])
-def test_reference_hooks_multirank_mpi_exchange(gold, nranks):
+@pytest.mark.parametrize("nranks,whole_step", [(2, False), (3, False), (2, True)])
+def test_reference_hooks_multirank_mpi_exchange(gold, nranks, whole_step):
     """same drop-in on 2 and 3 MPI ranks (all sharing the one GPU): the reference's own genEdgeSched schedule
     (SendCycle/RecvCycle slots) feeds tse_init, and the bndry_exchangeV replacement is the Fortran MPI callback of
     cuda_mod_hip.F90 (host-staged, MPICH is not GPU-aware).  Output must match the single-rank plain-Fortran reference."""
@@ -52,7 +60,8 @@ def test_reference_hooks_multirank_mpi_exchange(gold, nranks):
     out = tempfile.mkdtemp(prefix="tse_f90mr_")
     stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
                                                  out, os.path.join(ROOT, "tests", "golden", "vcoord"))
-    res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                         env=_env(whole_step))
     log = res.stdout.decode()
     assert "ref_harness done" in log, log[-3000:]
     q = np.empty_like(g["qdp_step6"])
