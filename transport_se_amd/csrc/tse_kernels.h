@@ -226,6 +226,18 @@ __device__ __forceinline__ void gather_sum(const RowGather& R, int j, int k, con
   // otherwise sink the adds below the loads and keep a second copy of all the values)
   asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : : "memory");
 }
+// The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
+// stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
+// instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
+__device__ __forceinline__ void store_row_pair(double* __restrict__ row0 /* &T[q][e][j*4][0] */, int k, bool live, const double v[4]) {
+  const bool odd = k & 1;
+  const double r0 = swz_xor4(odd ? v[0] : v[2]), r1 = swz_xor4(odd ? v[1] : v[3]);
+  if (live) {
+    double* p = row0 + (size_t)(odd ? 2 : 0) * TLEV + (k & ~1);
+    *reinterpret_cast<double2*>(p) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
+    *reinterpret_cast<double2*>(p + TLEV) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
+  }
+}
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
 __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* __restrict__ recvbuf, int nlyr_halo, double* __restrict__ dst,
                               size_t tps, int nelemd) {
@@ -297,14 +309,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   // whole step to drain and nothing waits for them (worth its 12 registers where few waves fit: the DSS-on-read kernels).
   struct Out { double x[4], mn, mx; bool ch; };   // ch: the bounds differ from what qmin/qmax already hold
   auto put = [&](const Out& o, int q) {
-    if (k < NLEV) {
-      // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
-      // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
-      double* tp = Tout + t_idx(GA.tps, q, e, j * 4, k);
-#pragma unroll
-      for (int i = 0; i < 4; i++) tp[(size_t)i * TLEV] = o.x[i];
-      if (j == 0 && o.ch) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
-    }
+    // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
+    // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
+    store_row_pair(Tout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, o.x);
+    if (k < NLEV && j == 0 && o.ch) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
   };
   RowGather RG;
   GatherRaw graw;                                        // raw own/neighbour values of the gathered input (DSS on read)
@@ -438,12 +446,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
       double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
       double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
       laplace_lean_row(D, L, x, l1);
-      if (k < NLEV) {
-        double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);   // scratch layout, as T
-#pragma unroll
-        for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = l1[i];
-        if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
-      }
+      store_row_pair(Bout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, l1);   // scratch layout, as T
+      if (k < NLEV && j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
     }
     return;
   }
@@ -455,13 +459,9 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   // the whole step and nothing waits for them.
   struct Out { double q[4], l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
-    if (k < NLEV) {
-      store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
-      double* bp = Bout + t_idx(GA.tps, q, e, j * 4, k);
-#pragma unroll
-      for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = o.l[i];
-      if (j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = o.mn; qmax[((size_t)e * qsize + q) * NLEV + k] = o.mx; }
-    }
+    if (k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
+    store_row_pair(Bout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, o.l);
+    if (k < NLEV && j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = o.mn; qmax[((size_t)e * qsize + q) * NLEV + k] = o.mx; }
   };
   auto step = [&](int q, const Out* prev, Out& cur) {
     double x[4];
