@@ -124,14 +124,18 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
     pmn[d] = n >= 0 ? in_min + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo : in_min + (size_t)e * m);
     pmx[d] = n >= 0 ? in_max + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m : in_max + (size_t)e * m);
   }
-  for (int l = threadIdx.x; l < m; l += 256) {
-    double mn = in_min[(size_t)e * m + l], mx = in_max[(size_t)e * m + l];
-    double nmn[8], nmx[8];   // all 16 neighbour loads in flight together
+  // two consecutive entries per lane: 16-byte loads/stores (m = qsize*72 is even; so are the halo offsets)
+  for (int l = 2 * threadIdx.x; l < m; l += 512) {
+    double2 mn = *reinterpret_cast<const double2*>(in_min + (size_t)e * m + l), mx = *reinterpret_cast<const double2*>(in_max + (size_t)e * m + l);
+    double2 nmn[8], nmx[8];   // all 16 neighbour loads in flight together
 #pragma unroll
-    for (int d = 0; d < 8; d++) { nmn[d] = pmn[d][l]; nmx[d] = pmx[d][l]; }
+    for (int d = 0; d < 8; d++) { nmn[d] = *reinterpret_cast<const double2*>(pmn[d] + l); nmx[d] = *reinterpret_cast<const double2*>(pmx[d] + l); }
 #pragma unroll
-    for (int d = 0; d < 8; d++) { mn = fmin(mn, nmn[d]); mx = fmax(mx, nmx[d]); }
-    out_min[(size_t)e * m + l] = mn; out_max[(size_t)e * m + l] = mx;
+    for (int d = 0; d < 8; d++) {
+      mn.x = fmin(mn.x, nmn[d].x); mn.y = fmin(mn.y, nmn[d].y);
+      mx.x = fmax(mx.x, nmx[d].x); mx.y = fmax(mx.y, nmx[d].y);
+    }
+    *reinterpret_cast<double2*>(out_min + (size_t)e * m + l) = mn; *reinterpret_cast<double2*>(out_max + (size_t)e * m + l) = mx;
   }
 }
 
