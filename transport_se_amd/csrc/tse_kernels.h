@@ -711,7 +711,8 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
       const double mn1 = quad_min(fmin(fmin(x1[0], x1[1]), fmin(x1[2], x1[3]))), mx1 = quad_max(fmax(fmax(x1[0], x1[1]), fmax(x1[2], x1[3])));
       if (j == 0) {
         const size_t mi = ((size_t)e * qsize + q) * NLEV + k0;
-        mn_out[mi] = mn0; mn_out[mi + 1] = mn1; mx_out[mi] = mx0; mx_out[mi + 1] = mx1;
+        *reinterpret_cast<double2*>(mn_out + mi) = make_double2(mn0, mn1);   // k0 is even: 16-byte aligned
+        *reinterpret_cast<double2*>(mx_out + mi) = make_double2(mx0, mx1);
       }
     }
   }
