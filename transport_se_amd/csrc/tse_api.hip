@@ -509,7 +509,7 @@ static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, doubl
     Scope s(c, "level");
     // out of place into the field's twin buffer (the source must stay intact while neighbours read it), then swap the two
     double** twin = var_levels == NLEV ? &c->lvl_tmp : &c->eta2;
-    hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
+    hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<LVL_UNITS>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
                        c->rspheremp, c->spheremp, var, var_levels, *twin, var_levels, c->recvbuf, nq + NLEV, nq, c->order);
     LAUNCH_CHECK();
     std::swap(*varp, *twin);

@@ -722,42 +722,58 @@ __global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, 
 // (prim_advection_mod.F90:911-919,943-957), out of place (the neighbours read src).  src/dst carry src_lev/dst_lev levels per
 // element (eta_dot_dpdn: nlev+1; the extra level is copied through), so no staging copies are needed and the caller just
 // swaps the two buffers.  Lanes flattened over (element slot, level, row) like k_dss_t; all gathers issued before any use.
+constexpr int LVL_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs (k, k+36) x 4 rows
 __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const int2* __restrict__ tab, const double* __restrict__ rspheremp,
                                                               const double* __restrict__ spheremp, const double* __restrict__ src, int src_lev,
                                                               double* __restrict__ dst, int dst_lev, const double* __restrict__ recvbuf,
                                                               int nlyr_halo, int lyr0, const int* __restrict__ order) {
-  const DssLane ln = dss_lane<NLEV * 4>(nelemd);
+  const DssLane ln = dss_lane<LVL_UNITS>(nelemd);
   if (!ln.live) return;
-  const int e = order[ln.slot], k = ln.r >> 2, j = ln.r & 3;
-  constexpr int NS = 8;
+  const int e = order[ln.slot], k = ln.r >> 2, j = ln.r & 3;   // the lane does levels k and k + NLEV/2 (the table lookup is shared)
+  constexpr int NS = 8, H = NLEV / 2;
   const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
   int2 tt[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
-  double v[4], sm[4], rs[4];
-  load4(src + ((size_t)e * src_lev + k) * 16 + j * 4, v);
+  double v0[4], v1[4], sm[4], rs[4];
+  const double* own = src + ((size_t)e * src_lev + k) * 16 + j * 4;
+  load4(own, v0); load4(own + (size_t)H * 16, v1);
   load4(spheremp + (size_t)e * 16 + j * 4, sm);
   load4(rspheremp + (size_t)e * 16 + j * 4, rs);
-  double a[NS], w[NS];
+  // every slot is one unconditional pair of loads (a load inside a divergent branch is waited for in the branch): an empty
+  // slot re-reads the lane's own point with weight 0, a remote one reads the halo (already weighted by the sender) with 1
+  const double* ap[NS]; const double* wp[NS]; size_t st[NS]; double wc[NS];
 #pragma unroll
-  for (int s = 0; s < NS; s++) {   // loads only (predicated per lane); an empty slot contributes +0.0
+  for (int s = 0; s < NS; s++) {
     const int2 t = tt[s];
-    a[s] = 0.0; w[s] = 1.0;
-    if (t.x >= 0) { a[s] = src[((size_t)t.x * src_lev + k) * 16 + t.y]; w[s] = spheremp[(size_t)t.x * 16 + t.y]; }
-    else if (t.x <= -2) a[s] = recvbuf[(size_t)(-(t.x + 2)) * nlyr_halo + lyr0 + k];   // packed with the sender's spheremp
+    ap[s] = own; wp[s] = spheremp + (size_t)e * 16 + j * 4; st[s] = (size_t)H * 16; wc[s] = 0.0;
+    if (t.x >= 0) { ap[s] = src + ((size_t)t.x * src_lev + k) * 16 + t.y; wp[s] = spheremp + (size_t)t.x * 16 + t.y; wc[s] = -1.0; }
+    else if (t.x <= -2) { ap[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + lyr0 + k; st[s] = H; wc[s] = 1.0; }
+  }
+  double a0[NS], a1[NS], w[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) { a0[s] = ap[s][0]; a1[s] = ap[s][st[s]]; w[s] = wp[s][0]; }
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const double ws = wc[s] < 0.0 ? w[s] : wc[s];   // local: the neighbour's spheremp; remote: 1; empty: 0
+    a0[s] = wc[s] == 0.0 ? 0.0 : ws * a0[s];        // (an empty slot adds +0.0 exactly, whatever it read)
+    a1[s] = wc[s] == 0.0 ? 0.0 : ws * a1[s];
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = sm[i] * v[i];
+  for (int i = 0; i < 4; i++) { v0[i] = sm[i] * v0[i]; v1[i] = sm[i] * v1[i]; }
+  v0[0] = v0[0] + a0[0]; v0[0] = v0[0] + a0[1]; v0[0] = v0[0] + a0[2];
+  v0[1] = v0[1] + a0[3];
+  v0[2] = v0[2] + a0[4];
+  v0[3] = v0[3] + a0[5]; v0[3] = v0[3] + a0[6]; v0[3] = v0[3] + a0[7];
+  v1[0] = v1[0] + a1[0]; v1[0] = v1[0] + a1[1]; v1[0] = v1[0] + a1[2];
+  v1[1] = v1[1] + a1[3];
+  v1[2] = v1[2] + a1[4];
+  v1[3] = v1[3] + a1[5]; v1[3] = v1[3] + a1[6]; v1[3] = v1[3] + a1[7];
 #pragma unroll
-  for (int s = 0; s < NS; s++) a[s] = tt[s].x >= 0 ? w[s] * a[s] : a[s];
-  v[0] = v[0] + a[0]; v[0] = v[0] + a[1]; v[0] = v[0] + a[2];
-  v[1] = v[1] + a[3];
-  v[2] = v[2] + a[4];
-  v[3] = v[3] + a[5]; v[3] = v[3] + a[6]; v[3] = v[3] + a[7];
-#pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
-  store4(dst + ((size_t)e * dst_lev + k) * 16 + j * 4, v);
-  if (k == NLEV - 1 && src_lev > NLEV && dst_lev > NLEV) {   // the interface below the last level is not DSS'd: copy it
+  for (int i = 0; i < 4; i++) { v0[i] = rs[i] * v0[i]; v1[i] = rs[i] * v1[i]; }
+  double* out = dst + ((size_t)e * dst_lev + k) * 16 + j * 4;
+  store4(out, v0); store4(out + (size_t)H * 16, v1);
+  if (k == H - 1 && src_lev > NLEV && dst_lev > NLEV) {   // the interface below the last level is not DSS'd: copy it
     double x[4];
     load4(src + ((size_t)e * src_lev + NLEV) * 16 + j * 4, x);
     store4(dst + ((size_t)e * dst_lev + NLEV) * 16 + j * 4, x);
