@@ -195,7 +195,7 @@ def test_limiter_edge_cases_through_the_step(ctx5):
 
 @pytest.mark.parametrize("qsize", [40, 200])
 def test_many_tracers(qsize):
-    """qsize > 36 exercises the tracer-chunk loops (k_remap walks tracers 36 at a time, k_dss_t2 5 at a time);
+    """qsize > 36 exercises the tracer-chunk loops (k_remap walks tracers 36 at a time, k_dss_t2 7 at a time);
     200 is BASELINE configs[4]'s stress size."""
     o = po.Oracle(2, qsize, nu_q=1e19, threads=8)
     elem = elem_from_oracle(o)

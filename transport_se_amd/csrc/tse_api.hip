@@ -19,7 +19,7 @@
 
 using namespace tse;
 
-static const int DSS_QB = 5;  // tracers per k_dss_t block
+static const int DSS_QB = 7;  // tracers per tracer-DSS block (3, 5, 7, 12 measured: 18.8, 18.4, 18.0, 18.0 ms for the final DSS)
 // TSE_FUSE_STAGE3=1 selects the variant that folds the first Laplacian into the stage-2 DSS and the second Laplacian
 // into the Laplacian's DSS (two field passes fewer, but 170-190 VGPRs -> 5 waves/CU: slower at present)
 // TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
