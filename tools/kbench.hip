@@ -9,6 +9,7 @@
 using namespace tse;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+constexpr int SLAB_THREADS = 320;   // one element per block: 72 levels x 4 rows = 288 active lanes
 __global__ __launch_bounds__(SLAB_THREADS) void k_copy_slab(int qsize, const double* __restrict__ in, double* __restrict__ out) {
   const int e = blockIdx.x, tid = threadIdx.x, k = tid >> 2, j = tid & 3;
   if (k >= NLEV) return;

@@ -9,7 +9,7 @@
 //   level fields   dp, divdp, divdp_proj, omega_p, dp3d [e][k][p]; vn0[e][k][c][p]; eta_dot_dpdn[e][73][p]
 //   bounds         qmin/qmax[e][q][k]
 //   metric         Dinv[e][p][4], metdet/rmetdet/spheremp/rspheremp[e][p]
-// Every slab kernel uses the row-per-lane layout of tse_device.h: block = one element, thread = (level k, row j),
+// Every slab kernel uses the row-per-lane layout of tse_device.h: thread = (slab (e,k) of the flattened index, row j),
 // looping over the tracers so that everything that depends on (e,k) only -- Vstar, dp, dp_star, the metric rows --
 // is computed once and stays in registers for all qsize tracers.
 #pragma once
@@ -18,7 +18,6 @@
 
 namespace tse {
 
-constexpr int SLAB_THREADS = 320;  // k_dss_t: block = element, 72 levels x 4 rows = 288 active lanes (4.5 waves)
 // The slab kernels (k_divdp, k_qminmax, k_advance, k_lap1) run over the flattened slab index s = e*NLEV + k instead: a
 // 72-level element is 4.5 waves, so element-sized blocks idle 10% of their lanes and -- worse -- come in units of 5 waves,
 // which leaves SIMD wave slots empty whenever the register budget allows 2 or 3 waves per SIMD (8 or 12 per CU).
@@ -30,7 +29,7 @@ constexpr int FLAT_THREADS = 256;
 #endif
 constexpr int TLEV = TSE_TLEV;
 // Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
-// XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[e][q][p][:]
+// XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[q][e][p][:]
 // rows through the same L2 (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
 struct SlabId { int e, k; bool live; };
 // `order` (optional): the strip walk of tse_api.hip -- consecutive slots are elements that are neighbours in both directions,
@@ -141,7 +140,7 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 
 // ---------------------------------------------------------------------------------------------------
 // DSS on read.  In the whole-step path the DSS'd field between two RK stages is never written to memory: the consuming
-// slab kernel assembles rspheremp*DSS(T) for its own row from the producer's pre-DSS scratch T[e][q][p][k] -- the lane's 4
+// slab kernel assembles rspheremp*DSS(T) for its own row from the producer's pre-DSS scratch T[q][e][p][k] -- the lane's 4
 // own points plus up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges,
 // then the corner) and the same inverse-mass multiply as k_dss_t2, so the value is bit-identical to what the DSS pass would
 // have stored.  That removes one read+write pass over the tracers per fused hand-over.
@@ -258,7 +257,7 @@ __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* _
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 // GIN: DSS on read (whole-step path).  1: the tracer input is rspheremp*DSS of the previous stage's pre-DSS scratch (passed
-// in Qn0, layout T[e][q][p][k]); 2: the Laplacian input `lap` is (RHS == 2 only).
+// in Qn0, layout T[q][e][p][k]); 2: the Laplacian input `lap` is (RHS == 2 only).
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
@@ -416,7 +415,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // ---------------------------------------------------------------------------------------------------
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
-// GIN == 1 (whole-step path): Qn0 is the stage-2 pre-DSS scratch T[e][q][p][k]; the DSS'd Qdp is assembled on read and
+// GIN == 1 (whole-step path): Qn0 is the stage-2 pre-DSS scratch T[q][e][p][k]; the DSS'd Qdp is assembled on read and
 // also stored to Qout (stage 3 reads it again in k_advance).
 template <int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
