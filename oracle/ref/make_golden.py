@@ -7,6 +7,7 @@ Only data is written (inputs and expected outputs); no reference source travels.
 
     python oracle/ref/make_golden.py            # ne2 fixtures (seconds)
     python oracle/ref/make_golden.py --long     # + ne8 12-day DCMIP 1-1 / 1-day 1-2 norms (minutes, 6 ranks)
+    python oracle/ref/make_golden.py --sfc      # only the space-filling-curve partition fixture (ref_sfc_partition.npz)
 """
 import argparse
 import json
@@ -112,13 +113,40 @@ def make_long(nranks=6):
     json.dump(res, open(os.path.join(GOLD, "ref_ne8_norms.json"), "w"), indent=1)
 
 
+SFC_CASES = ((2, 2), (4, 3), (5, 3), (6, 4), (7, 5), (8, 8), (9, 4), (10, 7), (15, 8), (30, 8))
+
+
+def make_sfc():
+    """owner rank of every element as the reference's genspacepart assigns it (read back from each rank's GlobalId list),
+    for face sizes that exercise the Hilbert (2), Peano (3), Cinco (5) levels, mixed factorisations, uneven chunk sizes and
+    the non-factorable fallback (ne=7)."""
+    out = {}
+    for ne, nranks in SFC_CASES:
+        outdir, _ = run(ne=ne, qsize=1, nsteps=0, tstep=300.0, nu_q=1e15, test=1, dumpfreq=0, nranks=nranks)
+        owner = -np.ones(6 * ne * ne, dtype=np.int16)
+        for r in range(nranks):
+            st = po.read_static(os.path.join(outdir, "static_000000_r%04d.bin" % r))
+            assert np.all(np.diff(st["gid"]) > 0)      # local order = ascending global number (metagraph_mod.F90:317-323)
+            owner[st["gid"] - 1] = r
+        assert owner.min() >= 0
+        out["owner_ne%d_np%d" % (ne, nranks)] = owner
+        print("sfc ne=%d nranks=%d: chunk sizes %s" % (ne, nranks, np.bincount(owner).tolist()))
+        import shutil
+        shutil.rmtree(outdir, ignore_errors=True)
+    np.savez_compressed(os.path.join(GOLD, "ref_sfc_partition.npz"), **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--sfc", action="store_true")
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--only-long", action="store_true")
     a = ap.parse_args()
     if not os.path.exists(HARNESS):
         subprocess.check_call(["make", "-C", HERE])
+    if a.sfc:
+        make_sfc()
+        sys.exit(0)
     if not a.only_long:
         make_ne2()
     if a.long or a.only_long:

@@ -21,7 +21,7 @@ def _run(world):
     hv = HvCoord()
     topo = cm.topology(NE); geo = cm.geometry(NE, topo)
     nelem = 6 * NE * NE
-    owner = partition(nelem, world)
+    owner = partition(NE, world)
     descs = [cm.edge_descriptors(topo, owner, r) for r in range(world)]
     hip = C.CDLL("libamdhip64.so")
     barrier = threading.Barrier(world)

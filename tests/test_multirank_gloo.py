@@ -46,7 +46,7 @@ def _worker(rank, world, port, field, ref, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     topo = cm.topology(NE)
-    owner = partition(6 * NE * NE, world)
+    owner = partition(NE, world)
     desc = cm.edge_descriptors(topo, owner, rank)
     mine = desc["elems"]
     own, send_src, recv_idx = _tables(desc)

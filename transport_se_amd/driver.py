@@ -3,12 +3,13 @@
 Mirrors prim_run_subcycle / prim_step (reference src/share/prim_driver_mod.F90:701-943) and TimeLevel_Qdp
 (time_mod.F90:85-109): rsplit tracer steps, each preceded by the prescribed-field refresh of prim_advance_exp
 (prim_advance_mod.F90:110-149), then vertical_remap.  One process per GPU; for world_size > 1 the elements are
-cut into contiguous chunks of the global element order and the DSS halo goes through torch.distributed
+cut into contiguous chunks of the reference's space-filling curve and the DSS halo goes through torch.distributed
 (backend nccl == RCCL over xGMI) inside the exchange callback of the C ABI (the bndry_exchangeV seam).
 """
 import numpy as np
 
 from . import cube_mesh as cm
+from .spacecurve import sfc_partition
 from .hip_mod import HipMod
 from .hybvcoord import HvCoord
 
@@ -16,11 +17,11 @@ NU_Q = {8: 6e16, 30: 1e15, 120: 1e13}     # test/run_ne8_tests.sh:27, run_ne30_t
 TSTEP = {8: 400.0, 30: 300.0, 120: 75.0}  # test/run_ne8_tests.sh:25, run_ne120_perf.sh:28
 
 
-def partition(nelem, nranks):
-    """contiguous chunks; the first mod(nelem,npart) ranks take one extra (spacecurve_mod.F90:1235-1263)"""
-    base, extra = divmod(nelem, nranks)
-    sizes = np.array([base + (1 if r < extra else 0) for r in range(nranks)])
-    return np.repeat(np.arange(nranks), sizes)
+def partition(ne, nranks):
+    """owner rank of every element (index = global element number - 1): contiguous chunks of the reference's
+    space-filling curve, the first mod(nelem,npart) ranks take one extra (spacecurve_mod.F90:1218-1273,
+    cube_mod.F90:1574-1633).  Local element order on a rank = ascending global number (metagraph_mod.F90:317-323)."""
+    return sfc_partition(ne, nranks)
 
 
 class HaloExchange:
@@ -98,7 +99,7 @@ class PrimRun:
         topo = cm.topology(ne)
         geo = cm.geometry(ne, topo)
         self.nelem = 6 * ne * ne
-        owner = partition(self.nelem, world)
+        owner = partition(ne, world)
         desc = cm.edge_descriptors(topo, owner, rank)
         mine = desc["elems"]
         self.mine = mine
