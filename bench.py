@@ -7,10 +7,13 @@
 A step = one prim_step of the reference's time loop (prescribed-field refresh + Prim_Advec_Tracers_remap_rk2: three
 RK-SSP euler_steps with limiter 8, hyperviscosity and DSS + time average) plus vertical_remap on every rsplit-th step.
 Workload at every N: ne120 / 72 levels / qsize=35 DCMIP 1-1 (BASELINE.json configs[2], configs[3]): the elements are
-sharded over the N GPUs (strong scaling), all state resident in HBM, fp64, synthetic (analytic DCMIP) data.
-Prints ONE JSON line on rank 0.
+sharded over the N GPUs along the reference's space-filling curve (strong scaling), all state resident in HBM, fp64,
+synthetic (analytic DCMIP) data; the DSS halo is exchanged inside the library with RCCL send/recv.
+Without WORLD_SIZE in the environment and N > 1 this script starts the N rank processes itself (fresh children through
+torch.distributed.run; this parent never touches a GPU) and exits with their status.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -32,43 +35,83 @@ KERNEL_NAMES = {"advance0": "k_advance<0,0>", "advance1": "k_advance<1,1>", "adv
                 "dss": "k_dss_t2<1>", "remap": "k_remap<1>"}
 
 
+def kernel_source_hash():
+    """identifies the kernel sources a PMC traffic profile was taken with (tools/pmc_traffic.py stores the same hash)"""
+    h = hashlib.sha256()
+    for f in ("tse_api.hip", "tse_kernels.h", "tse_device.h"):
+        h.update(open(os.path.join(ROOT, "transport_se_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(ne, qsize, n_gpus, group):
-    """HBM bytes per launch of the dominant kernel group from the committed PMC passes (profiles/), collected exactly as
-    MI355X_MICROARCH.md prescribes (separate --pmc runs, FETCH_SIZE doubled on gfx950); None when the workload differs"""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_traffic_ne120_q35.json")))
-        c = t["config"]
-        if (c["ne"], c["qsize"], c["n_gpus"]) == (ne, qsize, n_gpus) and os.environ.get("TSE_DSS_ON_READ", "1") != "0":
-            return t["kernels"][KERNEL_NAMES[group]]["hbm_bytes_per_launch"]
+    """(HBM bytes per launch of the dominant kernel, source file) from the newest committed PMC passes under profiles/ that
+    were collected with THIS build's kernel sources and workload (collected as MI355X_MICROARCH.md prescribes: separate --pmc
+    runs, FETCH_SIZE doubled on gfx950); (None, reason) otherwise -- counters cannot be read in the timed run itself."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            c = t["config"]
+            if (c["ne"], c["qsize"], c["n_gpus"]) != (ne, qsize, n_gpus) or os.environ.get("TSE_DSS_ON_READ", "1") == "0":
+                continue
+            if t.get("kernel_source_hash") != kernel_source_hash():
+                continue
+            return t["kernels"][KERNEL_NAMES[group]]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:  # noqa: BLE001
+            continue
+    return None, "no PMC profile of this build and workload under profiles/"
+
+
+def host_cores():
+    """(usable cores for this process, logical CPUs of the box, sockets)"""
+    total = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else total
+    try:   # cgroup v2 quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
     except Exception:  # noqa: BLE001
         pass
-    return None
+    sockets = 1
+    try:
+        ids = set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                ids.add(line.split(":")[1].strip())
+        sockets = max(1, len(ids))
+    except Exception:  # noqa: BLE001
+        pass
+    return usable, total, sockets
 
 
-def cpu_baseline(qsize, seconds_hint=20.0):
-    """the reference itself (oracle/_ref/ref_harness: unmodified reference modules, MPI ranks on the host cores) on a
-    bounded sample of the same workload; falls back to the C restatement (oracle/, OpenMP) if the binary is absent."""
-    import multiprocessing
-    cores = max(1, min(multiprocessing.cpu_count(), 16))
+def cpu_baseline(qsize):
+    """the reference itself (oracle/_ref/ref_harness: unmodified reference modules, one MPI rank per usable host core) on a
+    bounded sample of the same workload -- the ne30 mesh with the bench's qsize (1.7 GB per tracer field at qsize 35, far
+    beyond the caches, so the rate is the bandwidth-bound one), 6 tracer steps + 2 remaps, timing the same prim_run
+    region; falls back to the C restatement (oracle/, OpenMP) if the binary is absent."""
+    usable, total, sockets = host_cores()
+    cores = int(os.environ.get("TSE_CPU_RANKS", usable))
+    where = "%d ranks on %d usable of %d logical CPUs, %d socket(s)" % (cores, usable, total, sockets)
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     vdir = os.path.join(ROOT, "tests", "golden", "vcoord")
-    ne, nsteps = 16, 6
+    ne, nsteps = int(os.environ.get("TSE_CPU_NE", "30")), 6
     if os.path.exists(harness) and os.path.exists("/opt/conda/bin/mpiexec"):
         try:
             import tempfile
             out = tempfile.mkdtemp(prefix="tse_cpu_")
-            stdin = "%d %d %d %r %r 1 -1\n'%s'\n'%s'\n" % (ne, qsize, nsteps, 300.0, 7e15, out, vdir)
+            stdin = "%d %d %d %r %r 1 -1\n'%s'\n'%s'\n" % (ne, qsize, nsteps, 300.0, 1e15, out, vdir)
             env = dict(os.environ); env.pop("HIP_VISIBLE_DEVICES", None)
             # the reference keeps Qtens_biharmonic(np,np,nlev,qsize,nets:nete) on the stack (prim_advection_mod.F90:708)
             cmd = "ulimit -s unlimited 2>/dev/null || ulimit -s $(ulimit -H -s); exec /opt/conda/bin/mpiexec -n %d %s" % (cores, harness)
             res = subprocess.run(["bash", "-c", cmd], input=stdin.encode(),
-                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=env)
             for line in res.stdout.decode().splitlines():
                 if "tracer-DOF-steps/s" in line:
                     v = float(line.split("=")[1])
                     return dict(value=v, unit="tracer-DOF-steps/s", cores=cores, kind="reference",
-                                sample="ne%d/72L/qsize=%d DCMIP1-1, %d tracer steps + 2 remaps, reference Fortran/MPI on %d ranks"
-                                       % (ne, qsize, nsteps, cores))
+                                sample="ne%d/72L/qsize=%d DCMIP1-1, %d tracer steps + 2 remaps (prim_run region), reference Fortran/MPI: %s"
+                                       % (ne, qsize, nsteps, where))
+            print("cpu_baseline: reference harness printed no rate:\n" + res.stdout.decode()[-800:], file=sys.stderr)
         except Exception as ex:  # noqa: BLE001
             print("cpu_baseline: reference harness failed (%s); using the C port" % ex, file=sys.stderr)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -80,7 +123,17 @@ def cpu_baseline(qsize, seconds_hint=20.0):
     v = o.nelem * 16 * 72 * qsize * done / dt
     o.close()
     return dict(value=v, unit="tracer-DOF-steps/s", cores=cores, kind="port",
-                sample="ne%d/72L/qsize=%d DCMIP1-1, %d tracer steps + 1 remap, C restatement with %d OpenMP threads" % (ne, qsize, done, cores))
+                sample="ne%d/72L/qsize=%d DCMIP1-1, %d tracer steps + 1 remap, C restatement with %d OpenMP threads (%s)" % (ne, qsize, done, cores, where))
+
+
+def self_launch(a):
+    """start the N rank processes (fresh children; nothing in this process has touched a GPU) and relay their output"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -92,23 +145,32 @@ def main():
     ap.add_argument("--qsize", type=int, default=int(os.environ.get("TSE_BENCH_QSIZE", "35")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
-    backend = os.environ.get("TSE_DIST_BACKEND", "nccl")   # "gloo": rehearsal with host-staged slots (ranks may share a GPU)
-    local = local % max(torch.cuda.device_count(), 1)
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start N>1 ranks with `python bench.py --gpus N` or "
+                         "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (a.gpus, world))
+    import torch
+    import torch.distributed as dist
+    # TSE_EXCHANGE: "rccl" (default: in-library RCCL send/recv), "torch" (torch.distributed P2P in the exchange callback),
+    # "staged" (rehearsal: host-staged slots over gloo; the ranks may then share one GPU)
+    exchange = os.environ.get("TSE_EXCHANGE", "rccl")
+    ndev = torch.cuda.device_count()
+    if world > 1 and exchange != "staged" and ndev < world:
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (TSE_EXCHANGE=staged rehearses several ranks on one GPU)" % (world, ndev))
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     if world > 1:
-        if backend == "nccl":
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")   # single node; the container hostname may not resolve
+        if exchange == "torch":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo")   # control plane only: communicator id, barrier, max-over-ranks of the time
     from transport_se_amd.driver import PrimRun
-    run = PrimRun(a.ne, a.qsize, test_case=1, rank=rank, world=world, device=local, dist_mod=dist, torch_mod=torch,
-                  stage_through_host=(backend != "nccl"))
+    run = PrimRun(a.ne, a.qsize, test_case=1, rank=rank, world=world, device=local, dist_mod=dist, torch_mod=torch, exchange=exchange)
+    comm_rank, comm_world = run.hip.comm_info()
 
     def barrier():
         run.hip.synchronize(); torch.cuda.synchronize()
@@ -127,7 +189,7 @@ def main():
     np1_final = 2 if ((a.warmup + a.steps) % 2 == 1) else 1     # TimeLevel_Qdp: the last step wrote 3 - n0
     checksum = run.state_checksum(np1_final, torch)
     if world > 1:
-        dev = "cuda:%d" % local if backend == "nccl" else "cpu"
+        dev = "cuda:%d" % local if exchange == "torch" else "cpu"
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -144,26 +206,33 @@ def main():
         ms, n = ktimes[dom]
         dof_local = float(run.mine.size) * 16 * 72 * a.qsize
         ach = (KERNEL_BYTES_PER_DOF[dom] * dof_local / 1e9) / (ms / max(n, 1) / 1e3) if ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(a.ne, a.qsize, world, dom)
+        nb, ni = run.hip.boundary_layout()
         out = {
-            "metric": "advected tracer-DOF/sec (ne120, 72L, qsize=35) + DCMIP1-1 L2 vs ref",
-            "value": value, "unit": "tracer-DOF-steps/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup,
+            "metric": "advected tracer-DOF/sec (ne%d, 72L, qsize=%d) + DCMIP1-1 L2 vs ref" % (a.ne, a.qsize),
+            "value": value, "unit": "tracer-DOF-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (analytic DCMIP 1-1 fields, no files)",
             "config": {"workload": "ne%d DCMIP1-1 prim_run, NP=4, 72L, qsize=%d, rsplit=3, limiter8, nu_q=%g, tstep=%g; "
-                                   "%d elements sharded over %d GPU(s)" % (a.ne, a.qsize, run.nu_q, run.tstep, nelem_total, a.gpus),
-                       "ne": a.ne, "nlev": 72, "qsize": a.qsize, "elements_per_gpu": int(run.mine.size)},
+                                   "%d elements sharded over %d GPU(s) along the space-filling curve"
+                                   % (a.ne, a.qsize, run.nu_q, run.tstep, nelem_total, world),
+                       "ne": a.ne, "nlev": 72, "qsize": a.qsize, "elements_per_gpu": int(run.mine.size),
+                       "rank_boundary_elements": nb, "interior_elements": ni},
+            # what the communicator itself reports (ncclCommCount / ncclCommUserRank); 1 / "none" on a single GPU
+            "world_size": comm_world if run.exchange_kind == "rccl" else world, "exchange": run.exchange_kind,
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(a.ne, a.qsize, a.gpus, dom), "avg_ms": ms / max(n, 1), "launches": n,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_ms": ms / max(n, 1), "launches": n,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
-                         "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (a.gpus * HBM_PEAK_GBS * 1e9)},
+                         "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (world * HBM_PEAK_GBS * 1e9)},
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in ktimes.items()},
+            "kernel_source_hash": kernel_source_hash(),
             # wrap-around int64 sum of the bit patterns of the final Qdp over all ranks: equal for every --gpus N
             # (same steps/warmup) iff the result is bit-for-bit independent of the partition
             "state_checksum": checksum & 0xFFFFFFFFFFFFFFFF,
         }
-        if a.gpus == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.qsize)
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     run.close()
     if world > 1:
         dist.destroy_process_group()

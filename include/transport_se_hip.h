@@ -11,7 +11,7 @@
  *   vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,..) prim_advection_mod.F90:1279-1282 -> tse_vertical_remap
  * plus the whole-step call Prim_Advec_Tracers_remap_rk2 (prim_advection_mod.F90:579-640) -> tse_advec_tracers_remap_rk2,
  * which is the fast path (one call per tracer step, everything stays in HBM).
- * The Fortran-side binding is shown in INTEGRATION.md and shipped as transport_se_amd/fortran/hip_mod.F90.
+ * The Fortran-side binding is shown in INTEGRATION.md and shipped as transport_se_amd/fortran/cuda_mod_hip.F90.
  *
  * Conventions
  *   - All functions return 0 on success, nonzero on error (the Fortran side then calls abortmp, as the
@@ -50,6 +50,9 @@ typedef struct tse_ctx tse_ctx;
  *           entry per neighbouring (element, direction) pair is sent instead of one per column; len[s] = the number of
  *           shared edges + shared corners with that rank (tse_halo_layout gives the totals). */
 typedef int (*tse_exchange_fn)(void *user, double *sendbuf, double *recvbuf, int nlyr, int kind);
+/* The callback is the portable form of the seam (an MPI host keeps its own communicator: cuda_mod_hip.F90 passes
+ * MPI_Isend/Irecv).  The native form is tse_comm_init below: the library then performs the exchange itself with RCCL
+ * send/recv on its own streams and the callback is not used. */
 
 typedef struct {
   int nelemd;          /* elements on this rank */
@@ -73,13 +76,29 @@ typedef struct {
   /* neighbour-rank slots (0 for a single rank) */
   int nsend; const int *send_peer; const int *send_ptrP; const int *send_lengthP;
   int nrecv; const int *recv_peer; const int *recv_ptrP; const int *recv_lengthP;
-  tse_exchange_fn exchange; void *exchange_user;   /* may be NULL when nsend == nrecv == 0 */
+  tse_exchange_fn exchange; void *exchange_user;   /* may be NULL when nsend == nrecv == 0, or when tse_comm_init follows */
 } tse_init_args;
 
 int  tse_init(tse_ctx **ctx, const tse_init_args *args);
 void tse_finalize(tse_ctx *ctx);
 const char *tse_last_error(void);
 int  tse_synchronize(tse_ctx *ctx);
+
+/* ---- bndry_exchangeV inside the library: RCCL neighbour send/recv over xGMI (bndry_mod.F90:74-124) ----
+ * One communicator rank per tse_ctx/GPU.  Rank 0 obtains an id with tse_comm_unique_id and hands it to the other ranks
+ * by whatever the host has (MPI_Bcast in a Fortran/MPI host, a torch.distributed/gloo broadcast in the Python driver);
+ * every rank then calls tse_comm_init (collective).  send_peer/recv_peer of tse_init_args are ranks of this
+ * communicator.  Afterwards every DSS halo is one `ncclGroupStart; ncclRecv/ncclSend per neighbour slot; ncclGroupEnd`
+ * on the library's communication stream, with no host synchronisation; in the whole-step call the rank-boundary
+ * elements are computed first and the exchange runs under the interior elements (the reference's
+ * cuda_mod.F90:358-401,961-1005 ordering). */
+#define TSE_COMM_ID_BYTES 128
+int tse_comm_unique_id(void *id_out /* TSE_COMM_ID_BYTES */);
+int tse_comm_init(tse_ctx *ctx, const void *id /* TSE_COMM_ID_BYTES */, int rank, int nranks);
+/* rank / size as the communicator itself reports them (ncclCommUserRank/ncclCommCount); 0/1 without a communicator */
+int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
+/* number of local elements that touch another rank (computed first in every stage) and that do not */
+int tse_boundary_layout(tse_ctx *ctx, int *n_boundary, int *n_interior);
 
 /* elem(ie)%state%Qdp(np,np,nlev,qsize_d,2) <-> device, time level nt (1|2); qsize_d = host array extent */
 int tse_copy_qdp_h2d(tse_ctx *ctx, const double *qdp_elem1, size_t elem_stride, int qsize_d, int nt);
@@ -104,8 +123,14 @@ int tse_advec_tracers_remap_rk2(tse_ctx *ctx, double dt, int n0_qdp, int np1_qdp
 int tse_compute_divdp(tse_ctx *ctx);
 int tse_euler_step(tse_ctx *ctx, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier);
 int tse_qdp_time_avg(tse_ctx *ctx, int rkstage, int n0_qdp, int np1_qdp);
-/* vertical_remap; returns 2 on "negative layer thickness" (prim_advection_mod.F90:1323) */
+/* vertical_remap; returns 2 on "negative layer thickness" (prim_advection_mod.F90:1323).  The reference aborts the whole
+ * job there (abortmp = MPI_Abort): a caller with several ranks must escalate a return of 2 the same way (every rank
+ * exits non-zero), otherwise the healthy ranks block in the next halo exchange. */
 int tse_vertical_remap(tse_ctx *ctx, double dt, int np1_qdp);
+/* The library caches the element min/max of Qdp(np1)/dp that the last kernel of a tracer step emits and reuses them as
+ * the next step's first-stage bounds (prim_advection_mod.F90:765-779 recomputes them).  Every entry point that changes
+ * Qdp or dp drops the cache; a caller that writes state through tse_device_ptr must call this itself. */
+int tse_invalidate_cache(tse_ctx *ctx);
 
 /* qmin/qmax(nlev,qsize,nelemd) module state of prim_advection_mod (:459), for inspection: out[ie][q][k] */
 int tse_get_qminmax(tse_ctx *ctx, double *qmin, double *qmax);

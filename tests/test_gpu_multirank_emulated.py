@@ -58,6 +58,7 @@ def _run(world):
                 dst = rbuf + int(roff[i]) * nlyr * 8
                 rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(ln * nlyr * 8), C.c_int(3))
                 assert rc == 0
+            assert hip.hipDeviceSynchronize() == 0   # a D2D hipMemcpy may return early; recvbuf must be complete on return
             barrier.wait()
             return 0
 

@@ -1,14 +1,108 @@
-"""-m gpu: the RCCL leg of the halo exchange on the one GPU we have: torch.distributed backend "nccl" (= RCCL) with
-world_size 1, HaloExchange wrapping raw HIP device pointers (__cuda_array_interface__) and exchanging a slot with
-itself (peer = own rank).  Checks pointer wrapping is zero-copy and that isend/irecv on the wrapped buffers moves the
-bytes; the multi-rank slot logic itself is covered by tests/test_multirank_gloo.py (gloo) and
-tests/test_gpu_multirank_emulated.py (two tse_ctx on one GPU)."""
+"""-m gpu: the RCCL legs of the halo exchange on the one GPU we have.
+
+RCCL refuses two ranks of one communicator on the same device ("Duplicate GPU detected"), so a real multi-rank run cannot
+be staged on a 1-GPU box.  What can be checked here:
+  * the in-library exchange (tse_comm_init + ncclGroupStart/ncclRecv/ncclSend/ncclGroupEnd on the library's communication
+    stream, boundary-first split launches, event hand-over between the two streams) in LOOPBACK: a context that owns one
+    rank's share of a 3-rank partition, with every neighbour slot pointed at rank 0 of a 1-rank communicator, so that each
+    slot it sends comes back as the slot it receives.  The same loopback through the callback form of the seam (one
+    hipMemcpy sendbuf -> recvbuf) must give the same bits: same slot offsets, same message sizes, same ordering of pack,
+    exchange, unpack and compute -- everything except a second GPU.
+  * torch.distributed backend "nccl" (= RCCL) with world_size 1 for the `exchange="torch"` callback (HaloExchange wrapping raw
+    HIP device pointers).
+The multi-rank slot logic itself is covered by tests/test_multirank_gloo.py (gloo, CPU) and
+tests/test_gpu_multirank_emulated.py (several tse_ctx on one GPU, bit-for-bit against one context)."""
+import ctypes as C
 import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+NE, QSIZE, NU_Q, DT = 4, 3, 5e17, 900.0
+
+
+def _loopback_run(mode):
+    from transport_se_amd import cube_mesh as cm
+    from transport_se_amd.driver import partition
+    from transport_se_amd.hip_mod import HipMod
+    from transport_se_amd.hybvcoord import HvCoord
+    hv = HvCoord()
+    topo = cm.topology(NE); geo = cm.geometry(NE, topo)
+    owner = partition(NE, 3)
+    rank = max(range(3), key=lambda r: len(cm.edge_descriptors(topo, owner, r)["send"]))   # a rank with the most neighbour slots
+    d = cm.edge_descriptors(topo, owner, rank)
+    assert len(d["send"]) >= 1
+    mine = d["elems"]
+    sched = dict(send=[(0, p, l) for (_, p, l) in d["send"]], recv=[(0, p, l) for (_, p, l) in d["recv"]])   # every peer -> rank 0 (self)
+    elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine], spheremp=geo["spheremp"][mine],
+                rspheremp=geo["rspheremp"][mine], putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
+    hip_rt = C.CDLL("libamdhip64.so")
+    lens = {}
+
+    class Loop:
+        def set_minmax_layout(self, send_len, recv_len):
+            lens[1] = int(sum(send_len)); assert list(send_len) == list(recv_len)
+
+        def __call__(self, sbuf, rbuf, nlyr, kind):
+            n = lens[kind] * nlyr * 8
+            rc = hip_rt.hipMemcpy(C.c_void_p(rbuf), C.c_void_p(sbuf), C.c_size_t(n), C.c_int(3))
+            # a device-to-device hipMemcpy may return before the copy has run; the seam's contract is that recvbuf is
+            # complete when the callback returns (the library's streams do not synchronise with the null stream)
+            return rc or hip_rt.hipDeviceSynchronize()
+
+    lens[0] = sum(s[2] for s in sched["send"])
+    h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), QSIZE, NU_Q, device=0, schedule=sched,
+               exchange=Loop() if mode == "callback" else None)
+    if mode == "rccl":
+        h.comm_init(HipMod.comm_unique_id(), 0, 1)
+        assert h.comm_info() == (0, 1)
+    else:
+        assert h.comm_info() == (0, 1)      # no communicator: reported as a single rank
+    nb, ni = h.boundary_layout()
+    assert nb > 0 and nb + ni == mine.size
+    h.dcmip_init(1, geo["lat"][mine], geo["lon"][mine], hv.hyam, hv.hybm)
+    h.dcmip_set_initial()
+    assert h.prim_run_subcycle(DT, 2, 0) == 6                      # 6 tracer steps, 2 remaps, whole-step (DSS on read) path
+    q = h.fetch("qdp", (2, mine.size, QSIZE, 72, 4, 4)).copy()
+    dv = h.fetch("divdp_proj", (mine.size, 72, 4, 4)).copy()
+    # the per-stage API takes the other exchange route (everything on the compute stream); from the initial state again
+    h.dcmip_set_initial(); h.dcmip_step_inputs(0, DT); h.compute_divdp()
+    h.euler_step(2, 1, DT / 2, 3, 0); h.euler_step(2, 2, DT / 2, 1, 1); h.euler_step(2, 2, DT / 2, 2, 2); h.qdp_time_avg(3, 1, 2)
+    q2 = h.fetch("qdp", (2, mine.size, QSIZE, 72, 4, 4)).copy()
+    h.close()
+    return q, dv, q2
+
+
+def test_in_library_rccl_exchange_matches_callback_in_loopback():
+    qa, da, q2a = _loopback_run("callback")
+    qb, db, q2b = _loopback_run("rccl")
+    assert np.isfinite(qa).all() and qa.max() > 0
+    assert np.array_equal(qa, qb), "whole-step path: RCCL exchange differs from the callback exchange"
+    assert np.array_equal(da, db)
+    assert np.array_equal(q2a, q2b), "per-stage path: RCCL exchange differs from the callback exchange"
+
+
+def test_halo_without_transport_fails_loudly():
+    """neighbour slots, but neither a communicator nor a callback: the first step must fail with a message, not hang"""
+    from transport_se_amd import cube_mesh as cm
+    from transport_se_amd.driver import partition
+    from transport_se_amd.hip_mod import HipMod, TseError
+    from transport_se_amd.hybvcoord import HvCoord
+    hv = HvCoord()
+    topo = cm.topology(2); geo = cm.geometry(2, topo)
+    d = cm.edge_descriptors(topo, partition(2, 2), 0)
+    mine = d["elems"]
+    elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine], spheremp=geo["spheremp"][mine],
+                rspheremp=geo["rspheremp"][mine], putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
+    h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), 2, 1e19, device=0, schedule=dict(send=d["send"], recv=d["recv"]))
+    h.dcmip_init(1, geo["lat"][mine], geo["lon"][mine], hv.hyam, hv.hybm)
+    h.dcmip_set_initial()
+    with pytest.raises(TseError, match="neither tse_comm_init"):
+        h.prim_run_subcycle(1800.0, 1, 0)
+    with pytest.raises(TseError, match="outside the 1-rank communicator"):
+        h.comm_init(HipMod.comm_unique_id(), 0, 1)     # peer rank 1 does not exist in a 1-rank communicator
+    h.close()
 
 
 def test_halo_exchange_on_rccl_self_peer():

@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from transport_se_amd import cube_mesh as cm
-from transport_se_amd.driver import HaloExchange, partition
+from transport_se_amd.driver import HaloExchange, check_schedules_match, partition
 
 NE, NLYR = 4, 5
 
@@ -54,6 +54,10 @@ def _worker(rank, world, port, field, ref, q):
     sendbuf = np.zeros((len(send_src), NLYR)); recvbuf = np.zeros((len(recv_idx), NLYR))
     for c, (e, p) in enumerate(send_src):                         # k_pack
         sendbuf[c] = f[e, :, p]
+    # entries of the compact min/max exchange per slot = (element, direction) pairs whose first column lies in the slot (tse_init)
+    starts = sorted(int(c) for c in desc["putmapP"].reshape(-1) if c >= 0)
+    mm = [sum(1 for c in starts if ptr - 1 <= c < ptr - 1 + ln) for (_, ptr, ln) in desc["send"]]
+    check_schedules_match(desc, (mm, mm), rank, dist)            # raises on any asymmetry between the ranks' slot lists
     ex = HaloExchange(desc, "cpu", dist, torch)
     assert ex(sendbuf.ctypes.data, recvbuf.ctypes.data, NLYR) == 0
     out = f.copy()                                                # k_dss: gather in the reference's order

@@ -33,7 +33,8 @@ def build(force=False, verbose=False):
         return SO
     # -fno-honor-nans: value-preserving (no reassociation, no reciprocal tricks); it only lets the compiler drop the
     # v_max_f64 x,x "canonicalize" it otherwise puts in front of every fmin/fmax operand (6 per limiter iteration)
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-honor-nans", "-shared", "-fPIC", "-o", SO, SRC[0]]
+    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-honor-nans", "-shared", "-fPIC", "-o", SO, SRC[0],
+           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the in-library bndry_exchangeV (tse_comm_init)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -47,7 +48,9 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_set_derived", "tse_set_divdp", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
-           "tse_halo_layout", "tse_halo_minmax_layout"]
+           "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_info",
+           "tse_boundary_layout", "tse_invalidate_cache"]
+COMM_ID_BYTES = 128
 
 
 def lib():
@@ -84,5 +87,10 @@ def lib():
     L.tse_timing.argtypes = [vp, i]
     L.tse_halo_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.tse_halo_minmax_layout.argtypes = [vp, vp, vp]
+    L.tse_comm_unique_id.argtypes = [vp]
+    L.tse_comm_init.argtypes = [vp, vp, i, i]
+    L.tse_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.tse_boundary_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.tse_invalidate_cache.argtypes = [vp]
     _lib = L
     return L

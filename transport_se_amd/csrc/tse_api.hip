@@ -2,8 +2,12 @@
 //
 // Owns all device memory for the run (as cuda_mod owns qdp_d etc., reference cuda_mod.F90:74-106), converts the
 // reference's edge descriptors (putmapP/getmapP/reverse + Send/RecvCycle slots) into on-device gather tables once
-// at init, and sequences the kernels of tse_kernels.h on one HIP stream.
+// at init, and sequences the kernels of tse_kernels.h on two HIP streams: the compute stream and -- when the rank has
+// neighbour ranks -- a communication stream that carries pack -> RCCL send/recv -> unpack of the rank-boundary columns
+// while the compute stream works on the interior elements (the reference's own accelerator seam orders its work the
+// same way: cuda_mod.F90:358-401,961-1005; the exchange it replaces is bndry_mod.F90:74-124).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -20,11 +24,8 @@
 using namespace tse;
 
 static const int DSS_QB = 7;  // tracers per tracer-DSS block (3, 5, 7, 12 measured: 18.8, 18.4, 18.0, 18.0 ms for the final DSS)
-// TSE_FUSE_STAGE3=1 selects the variant that folds the first Laplacian into the stage-2 DSS and the second Laplacian
-// into the Laplacian's DSS (two field passes fewer, but 170-190 VGPRs -> 5 waves/CU: slower at present)
 // TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
 static bool dss_on_read() { const char* e = getenv("TSE_DSS_ON_READ"); return !(e && e[0] == '0'); }
-static bool fuse_stage3() { static int v = -1; if (v < 0) { const char* e = getenv("TSE_FUSE_STAGE3"); v = (e && e[0] == '1') ? 1 : 0; } return v == 1; }
 
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -32,6 +33,7 @@ static int fail(const char* fmt, ...) {
   return 1;
 }
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_)); } while (0)
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail("%s:%d %s: %s", __FILE__, __LINE__, #x, ncclGetErrorString(r_)); } while (0)
 
 struct KTimer { double ms = 0; long n = 0; };
 
@@ -52,14 +54,21 @@ struct tse_ctx {
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
   int* bad = nullptr;
   int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
-  // halo
+  // halo: one slot per neighbour rank (Schedule(1)%SendCycle/RecvCycle), entries per slot for the two exchange kinds
   int ncol_send = 0, ncol_recv = 0, nlyr_halo = 0;
   int nmm_send = 0, nmm_recv = 0;              // entries of the compact min/max exchange
-  std::vector<int> mm_send_len, mm_recv_len;   // per slot
+  std::vector<int> send_peer, recv_peer, send_len, recv_len;   // kind 0: edge-buffer columns per slot
+  std::vector<int> mm_send_len, mm_recv_len;                   // kind 1: (element, direction) pairs per slot
   int2* mm_send_src = nullptr;
-  double *sendbuf = nullptr, *recvbuf = nullptr;
-  bool own_halo = false;
+  double *sendbuf = nullptr, *recvbuf = nullptr, *sendbuf_mm = nullptr, *recvbuf_mm = nullptr;
   tse_exchange_fn exchange = nullptr; void* exchange_user = nullptr;
+  // in-library exchange: RCCL communicator + communication stream; elements that touch another rank / that do not
+  ncclComm_t comm = nullptr;
+  hipStream_t comm_stream = nullptr;
+  std::vector<hipEvent_t> sync_events; size_t sync_next = 0;
+  int *ord_bnd = nullptr, *ord_int = nullptr;
+  int n_bnd = 0, n_int = 0;
+  bool halo() const { return ncol_send || ncol_recv; }
   // dcmip
   int dcmip_test = 0;
   double *lat = nullptr, *lon = nullptr, *zm = nullptr, *zi = nullptr, *pint = nullptr, *dph = nullptr;
@@ -82,9 +91,6 @@ struct tse_ctx {
 };
 
 const char* tse_last_error(void) { return g_err; }
-
-// element walk order of the slab kernels: plain element order; TSE_SLAB_ORDER=1 = the DSS strip walk (measured: no gain)
-static const int* slab_order(tse_ctx* c) { const char* e = getenv("TSE_SLAB_ORDER"); return (e && e[0] == '1') ? c->order : nullptr; }
 
 template <class T>
 static int dalloc(T** p, size_t n) {
@@ -137,14 +143,8 @@ static void gather_strided(std::vector<double>& out, const double* base, size_t 
     memcpy(&out[(size_t)e * cnt], (const char*)base + (size_t)e * stride_bytes, sizeof(double) * cnt);
 }
 
-int tse_init(tse_ctx** out, const tse_init_args* a) {
-  if (!out || !a) return fail("tse_init: null argument");
-  if (a->limiter_option != 8) return fail("tse_init: only limiter_option=8 is supported (got %d)", a->limiter_option);
-  if (a->nelemd <= 0 || a->qsize <= 0) return fail("tse_init: nelemd=%d qsize=%d", a->nelemd, a->qsize);
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("tse_init: no HIP device (this library has no CPU fallback)");
-  tse_ctx* c = new tse_ctx();
-  if (a->device >= 0) { if (hipSetDevice(a->device) != hipSuccess) { delete c; return fail("hipSetDevice(%d) failed", a->device); } }
+static int init_impl(tse_ctx* c, const tse_init_args* a) {
+  if (a->device >= 0) HIPCHK(hipSetDevice(a->device));
   HIPCHK(hipGetDevice(&c->device));
   c->nelemd = a->nelemd; c->qsize = a->qsize; c->nu_q = a->nu_q; c->ps0 = a->ps0; c->rsplit = a->rsplit;
   c->exchange = a->exchange; c->exchange_user = a->exchange_user;
@@ -154,9 +154,8 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   const int n = a->nelemd;
   std::vector<double> h;
   gather_strided(h, a->Dinv, a->Dinv_stride, n, 64);
-  {  // Dinv(a,b,i,j) in Fortran memory = [p][b][a] -> keep as is: [e][p][4] = {D11, D21, D12, D22}
-    if (upload(&c->Dinv, h)) return 1;
-  }
+  // Dinv(a,b,i,j) in Fortran memory = [p][b][a] -> keep as is: [e][p][4] = {D11, D21, D12, D22}
+  if (upload(&c->Dinv, h)) return 1;
   gather_strided(h, a->metdet, a->metdet_stride, n, 16);       if (upload(&c->metdet, h)) return 1;
   gather_strided(h, a->rmetdet, a->rmetdet_stride, n, 16);     if (upload(&c->rmetdet, h)) return 1;
   gather_strided(h, a->spheremp, a->spheremp_stride, n, 16);   if (upload(&c->spheremp, h)) return 1;
@@ -189,11 +188,15 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
       } else { own_e[pm] = e; own_p[pm] = corner_point(d); }
     }
   c->ncol_send = 0;
-  for (int s = 0; s < a->nsend; s++)
+  for (int s = 0; s < a->nsend; s++) {
+    c->send_peer.push_back(a->send_peer[s]); c->send_len.push_back(a->send_lengthP[s]);
     for (int i = 0; i < a->send_lengthP[s]; i++) send_idx[a->send_ptrP[s] - 1 + i] = c->ncol_send++;
+  }
   c->ncol_recv = 0;
-  for (int s = 0; s < a->nrecv; s++)
+  for (int s = 0; s < a->nrecv; s++) {
+    c->recv_peer.push_back(a->recv_peer[s]); c->recv_len.push_back(a->recv_lengthP[s]);
     for (int i = 0; i < a->recv_lengthP[s]; i++) recv_idx[a->recv_ptrP[s] - 1 + i] = c->ncol_recv++;
+  }
   // compact min/max exchange: one entry per (element, direction) pair that crosses the rank boundary.  Sender and
   // receiver enumerate the edge/corner start columns of a slot in increasing column order, which is the same sequence
   // on both ranks because the two slots are mirror images (the sender writes where the receiver reads).
@@ -216,7 +219,6 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
     }
     c->mm_recv_len.push_back(cnt);
   }
-  if ((c->ncol_send || c->ncol_recv) && !a->exchange) { return fail("tse_init: neighbour-rank slots given but no exchange callback"); }
 
   std::vector<int2> send_src(c->ncol_send);
   for (int col = 0; col < maxcol; col++)
@@ -259,7 +261,7 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   }
   if (upload(&c->dss_tab, tab) || upload(&c->nbr, nbr) || upload(&c->send_src, send_src) || upload(&c->mm_send_src, mm_src)) return 1;
   {
-    // Walk order for the gather kernels.  Each XCD processes a contiguous range of elements (L2 is per XCD); inside
+    // Walk order for the DSS kernels.  Each XCD processes a contiguous range of elements (L2 is per XCD); inside
     // the range we follow a greedy neighbour walk over the local element graph (west/east/south/north links) in
     // strips, so that the elements whose edge values a block gathers were touched by the same XCD a few blocks
     // earlier instead of a whole row of the face earlier.  Pure scheduling: results do not depend on it.
@@ -287,6 +289,18 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
     if (W <= 0) for (int e = 0; e < n; e++) order[e] = e;
     if (upload(&c->order, order)) return 1;
   }
+  {
+    // Boundary-first ordering (the reference's recv_external_indices / recv_internal_indices, cuda_mod.F90:358-401): the
+    // elements that own a column of a send slot are computed first in every stage, so that their halo travels while
+    // the remaining elements are computed.
+    std::vector<char> isb(n, 0);
+    for (const int2& s : send_src) isb[s.x] = 1;
+    for (const int2& s : mm_src) isb[s.x] = 1;
+    std::vector<int> ob, oi;
+    for (int e = 0; e < n; e++) (isb[e] ? ob : oi).push_back(e);
+    c->n_bnd = (int)ob.size(); c->n_int = (int)oi.size();
+    if (upload(&c->ord_bnd, ob) || upload(&c->ord_int, oi)) return 1;
+  }
 
   // ---- state -------------------------------------------------------------------------------------
   const size_t lev = c->lev(), trc = c->trc();
@@ -307,16 +321,38 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
   HIPCHK(hipMemset(c->qmin, 0, mm * 8)); HIPCHK(hipMemset(c->qmax, 0, mm * 8));
   HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
-  // halo buffers sized for the largest exchange: 3*qsize*nlev layers is what the reference allocates
-  // (prim_advection_mod.F90:488); we need max(qsize*nlev + nlev, 2*qsize*nlev)
-  c->nlyr_halo = std::max(c->qsize * NLEV + NLEV, 2 * c->qsize * NLEV);
-  if (c->ncol_send || c->ncol_recv) {
-    if (dalloc(&c->sendbuf, (size_t)std::max(1, c->ncol_send) * c->nlyr_halo) || dalloc(&c->recvbuf, (size_t)std::max(1, c->ncol_recv) * c->nlyr_halo)) return 1;
-    c->own_halo = true;
+  // Halo buffers.  The reference sizes one aliased buffer for 3*qsize*nlev layers (prim_advection_mod.F90:488); here the
+  // tracer DSS (qsize*nlev + nlev layers per column) and the element-constant min/max exchange (2*qsize*nlev per
+  // (element, direction) pair) have their own buffers, so that the two exchanges of stage 3 can be in flight together.
+  c->nlyr_halo = c->qsize * NLEV + NLEV;
+  if (c->halo()) {
+    const size_t m2 = (size_t)2 * c->qsize * NLEV;
+    if (dalloc(&c->sendbuf, (size_t)std::max(1, c->ncol_send) * c->nlyr_halo) || dalloc(&c->recvbuf, (size_t)std::max(1, c->ncol_recv) * c->nlyr_halo) ||
+        dalloc(&c->sendbuf_mm, (size_t)std::max(1, c->nmm_send) * m2) || dalloc(&c->recvbuf_mm, (size_t)std::max(1, c->nmm_recv) * m2)) return 1;
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = greatest priority
+    HIPCHK(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+    c->sync_events.assign(16, nullptr);
+    for (hipEvent_t& e : c->sync_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+
+int tse_init(tse_ctx** out, const tse_init_args* a) {
+  if (!out || !a) return fail("tse_init: null argument");
+  *out = nullptr;
+  if (a->limiter_option != 8) return fail("tse_init: only limiter_option=8 is supported (got %d)", a->limiter_option);
+  if (a->nelemd <= 0 || a->qsize <= 0) return fail("tse_init: nelemd=%d qsize=%d", a->nelemd, a->qsize);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("tse_init: no HIP device (this library has no CPU fallback)");
+  tse_ctx* c = new tse_ctx();
+  if (init_impl(c, a)) {   // release whatever was allocated before the failure (the message in g_err survives)
+    tse_finalize(c);
+    return 1;
+  }
   *out = c;
   return 0;
 }
@@ -324,24 +360,63 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
 void tse_finalize(tse_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+  if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
-                  c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
+                  c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
+                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  if (c->own_halo) { (void)hipFree(c->sendbuf); (void)hipFree(c->recvbuf); }
   resolve_timers(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-  (void)hipStreamDestroy(c->stream);
+  for (hipEvent_t e : c->sync_events) if (e) (void)hipEventDestroy(e);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
-int tse_synchronize(tse_ctx* c) { HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+int tse_synchronize(tse_ctx* c) {
+  if (c->comm_stream) HIPCHK(hipStreamSynchronize(c->comm_stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
 
 int tse_halo_layout(tse_ctx* c, int* ns, int* nr) { if (ns) *ns = c->ncol_send; if (nr) *nr = c->ncol_recv; return 0; }
 int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   for (size_t i = 0; i < c->mm_send_len.size(); i++) send_len[i] = c->mm_send_len[i];
   for (size_t i = 0; i < c->mm_recv_len.size(); i++) recv_len[i] = c->mm_recv_len[i];
+  return 0;
+}
+int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
+int tse_invalidate_cache(tse_ctx* c) { c->mm_valid = 0; return 0; }
+
+// ---- RCCL communicator ----------------------------------------------------------------------------
+int tse_comm_unique_id(void* id_out) {
+  static_assert(sizeof(ncclUniqueId) == TSE_COMM_ID_BYTES, "ncclUniqueId size");
+  if (!id_out) return fail("tse_comm_unique_id: null argument");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+int tse_comm_init(tse_ctx* c, const void* id_in, int rank, int nranks) {
+  if (!c || !id_in) return fail("tse_comm_init: null argument");
+  if (c->comm) return fail("tse_comm_init: communicator already initialised");
+  if (rank < 0 || rank >= nranks) return fail("tse_comm_init: rank %d of %d", rank, nranks);
+  for (int p : c->send_peer) if (p < 0 || p >= nranks) return fail("tse_comm_init: send peer %d outside the %d-rank communicator", p, nranks);
+  for (int p : c->recv_peer) if (p < 0 || p >= nranks) return fail("tse_comm_init: recv peer %d outside the %d-rank communicator", p, nranks);
+  HIPCHK(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof id);
+  NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+  return 0;
+}
+int tse_comm_info(tse_ctx* c, int* rank, int* nranks) {
+  int r = 0, n = 1;
+  if (c->comm) { NCCLCHK(ncclCommUserRank(c->comm, &r)); NCCLCHK(ncclCommCount(c->comm, &n)); }
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
   return 0;
 }
 
@@ -426,108 +501,139 @@ int tse_compute_divdp(tse_ctx* c) {
   return 0;
 }
 
-// bndry_exchangeV on the packed rank-boundary columns (no-op on one rank)
-static int halo_exchange(tse_ctx* c, int nlyr, int kind = 0) {
-  if (!c->ncol_send && !c->ncol_recv) return 0;
-  HIPCHK(hipStreamSynchronize(c->stream));
-  if (c->exchange(c->exchange_user, c->sendbuf, c->recvbuf, nlyr, kind)) return fail("exchange callback failed");
+// bndry_exchangeV on the packed rank-boundary columns, ordered on stream `st` (no-op on one rank).
+// kind 0: sendbuf/recvbuf, one entry per edge-buffer column; kind 1: the compact min/max buffers.
+// With a communicator: one grouped RCCL receive + send per neighbour slot enqueued on `st`, no host synchronisation
+// (bndry_mod.F90:74-112 posts all sends and receives, then waits).  Otherwise the host's callback, after `st` has drained.
+static int halo_exchange(tse_ctx* c, int nlyr, int kind, hipStream_t st) {
+  if (!c->halo()) return 0;
+  double* sb = kind ? c->sendbuf_mm : c->sendbuf;
+  double* rb = kind ? c->recvbuf_mm : c->recvbuf;
+  if (c->comm) {
+    const std::vector<int>& ls = kind ? c->mm_send_len : c->send_len;
+    const std::vector<int>& lr = kind ? c->mm_recv_len : c->recv_len;
+    NCCLCHK(ncclGroupStart());
+    size_t off = 0;
+    for (size_t i = 0; i < lr.size(); i++) {
+      if (lr[i]) NCCLCHK(ncclRecv(rb + off * nlyr, (size_t)lr[i] * nlyr, ncclDouble, c->recv_peer[i], c->comm, st));
+      off += lr[i];
+    }
+    off = 0;
+    for (size_t i = 0; i < ls.size(); i++) {
+      if (ls[i]) NCCLCHK(ncclSend(sb + off * nlyr, (size_t)ls[i] * nlyr, ncclDouble, c->send_peer[i], c->comm, st));
+      off += ls[i];
+    }
+    NCCLCHK(ncclGroupEnd());
+    return 0;
+  }
+  if (!c->exchange) return fail("halo exchange: this rank has neighbour ranks but neither tse_comm_init was called nor an exchange callback given");
+  HIPCHK(hipStreamSynchronize(st));
+  if (c->exchange(c->exchange_user, sb, rb, nlyr, kind)) return fail("exchange callback failed");
   return 0;
 }
 
+// ---- pack / unpack launches (on stream st) ----
+// scratch field (T or B) -> sendbuf layers [0, qsize*nlev) of nlyr_halo
+static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int nlyr_halo) {
+  const int nq = c->qsize * NLEV;
+  if (!c->ncol_send) return 0;
+  size_t tot = (size_t)c->ncol_send * nq;
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_send, nq, c->send_src, scratch,
+                     (const double*)nullptr, c->sendbuf, nlyr_halo, 0, c->tps, 0);
+  LAUNCH_CHECK();
+  return 0;
+}
+// spheremp*var -> sendbuf layers [qsize*nlev, +nlev).  eta_dot_dpdn carries nlev+1 levels per element; levels 1:nlev are exchanged (:835-837)
+static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_levels) {
+  const int nq = c->qsize * NLEV;
+  if (!c->ncol_send || !var) return 0;
+  size_t tv = (size_t)c->ncol_send * NLEV;
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var,
+                     c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0, var_levels);
+  LAUNCH_CHECK();
+  return 0;
+}
+static int pack_minmax(tse_ctx* c, hipStream_t st) {
+  const int m = c->qsize * NLEV;
+  if (!c->nmm_send) return 0;
+  size_t tot = (size_t)c->nmm_send * m;
+  hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
+                     c->qmin, c->qmax, c->sendbuf_mm, 2 * m, 0);
+  LAUNCH_CHECK();
+  return 0;
+}
 // DSS on read: copy the received tracer halo behind the planes of the scratch field the next slab kernel gathers from
-static int unpack_halo(tse_ctx* c, double* field, int nlyr_halo) {
+static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo) {
   if (!c->ncol_recv) return 0;
   const int nq = c->qsize * NLEV;
   size_t tot = (size_t)c->ncol_recv * nq;
-  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->tps,
+  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->tps,
                      c->nelemd);
   LAUNCH_CHECK();
   return 0;
 }
 
-// min/max over neighbours of qmin/qmax (in place; double-buffered on the device)
-static int neighbor_minmax(tse_ctx* c) {
+// min/max over the <= 8 neighbours of qmin/qmax (double-buffered on the device); the halo part must have arrived
+static int nbr_minmax_kernel(tse_ctx* c) {
   const int m = c->qsize * NLEV;
-  if (c->nmm_send) {
-    size_t tot = (size_t)c->nmm_send * m;
-    hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nmm_send, m, c->mm_send_src,
-                       c->qmin, c->qmax, c->sendbuf, 2 * m, 0);
-    LAUNCH_CHECK();
-  }
-  if (halo_exchange(c, 2 * m, 1)) return 1;
   {
     Scope s(c, "minmax");
     hipLaunchKernelGGL(k_nbr_minmax, dim3(8 * ((c->nelemd + 7) / 8)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,
-                       c->qmax, c->qmin2, c->qmax2, c->recvbuf, 2 * m);
+                       c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m);
     LAUNCH_CHECK();
   }
   std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
   return 0;
 }
+// neighbor_minmax (viscosity_mod.F90:748-816), everything on the compute stream (per-stage API)
+static int neighbor_minmax(tse_ctx* c) {
+  if (pack_minmax(c, c->stream)) return 1;
+  if (halo_exchange(c, 2 * c->qsize * NLEV, 1, c->stream)) return 1;
+  return nbr_minmax_kernel(c);
+}
 
-// DSS (+ inverse mass matrix) of a tracer-sized field src -> dst, together with the extra level variable
-// (spheremp*var packed behind the tracers: nlyr = qsize*nlev + nlev as edgeAdv_p1, prim_advection_mod.F90:497,911-919)
-static int dss_tracers_and_var(tse_ctx* c, const double* src, double* dst, double** varp /* &c->eta, &c->omega_p, &c->divdp_proj or null */,
-                               int var_levels, const double* Qn0_avg /* non-null: fuse qdp_time_avg */, int mode3 = 0, double rdt = 0.0,
-                               bool skip_tracers = false /* DSS on read: the next stage assembles the tracers itself */) {
+// DSS of the extra level variable of a stage (divdp_proj / eta_dot_dpdn / omega_p): rspheremp*DSS(spheremp*var), remote
+// contributions from recvbuf layers [qsize*nlev, +nlev) (prim_advection_mod.F90:911-919,943-957)
+static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
+  if (!varp) return 0;
   const int nq = c->qsize * NLEV;
-  const double* var = varp ? *varp : nullptr;
-  if (c->ncol_send) {
-    size_t tot = (size_t)c->ncol_send * nq;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, src,
-                       (const double*)nullptr, c->sendbuf, nq + NLEV, 0, c->tps, 0);
-    LAUNCH_CHECK();
-    if (var) {   // eta_dot_dpdn carries nlev+1 levels per element; levels 1:nlev are exchanged (:835-837)
-      size_t tv = (size_t)c->ncol_send * NLEV;
-      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, NLEV, c->send_src, var,
-                         c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0, var_levels);
-      LAUNCH_CHECK();
-    }
-  }
-  if (halo_exchange(c, nq + NLEV)) return 1;
-  if (skip_tracers && unpack_halo(c, const_cast<double*>(src), nq + NLEV)) return 1;
-  if (!skip_tracers) {
-    Scope s(c, "dss");
-    const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-    const dim3 grid(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd) * nqc);
-    const dim3 grid2(8 * dss2_blocks_per_xcd(c->nelemd) * nqc);
-    // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: (qsize*72 + 72) always is
-    if (Qn0_avg)
-      hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         Qn0_avg, c->recvbuf, nq + NLEV, c->order, (const double*)c->dp, c->qmin2, c->qmax2, c->tps);
-    else if (mode3) {
-      DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = rdt; X.dp = c->dp; X.divdp_proj = c->divdp_proj; X.qmin = c->qmin; X.qmax = c->qmax;
-      X.lapout = c->B; X.tps = c->tps;
-      hipLaunchKernelGGL(k_dss_t<3>, grid, dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, X, c->order);
-    } else
-      hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                         (const double*)nullptr, c->recvbuf, nq + NLEV, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr, c->tps);
-    LAUNCH_CHECK();
-  }
-  if (var) {
-    Scope s(c, "level");
-    // out of place into the field's twin buffer (the source must stay intact while neighbours read it), then swap the two
-    double** twin = var_levels == NLEV ? &c->lvl_tmp : &c->eta2;
-    hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<LVL_UNITS>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
-                       c->rspheremp, c->spheremp, var, var_levels, *twin, var_levels, c->recvbuf, nq + NLEV, nq, c->order);
-    LAUNCH_CHECK();
-    std::swap(*varp, *twin);
-  }
+  Scope s(c, "level");
+  // out of place into the field's twin buffer (the source must stay intact while neighbours read it), then swap the two
+  double** twin = var_levels == NLEV ? &c->lvl_tmp : &c->eta2;
+  hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<LVL_UNITS>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
+                     c->rspheremp, c->spheremp, *varp, var_levels, *twin, var_levels, c->recvbuf, nq + NLEV, nq, c->order);
+  LAUNCH_CHECK();
+  std::swap(*varp, *twin);
+  return 0;
+}
+// tracer DSS pass src (scratch layout) -> dst (standard layout), optionally fused with qdp_time_avg and the next step's bounds
+static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, int nlyr_halo) {
+  Scope s(c, "dss");
+  const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
+  const dim3 grid2(8 * dss2_blocks_per_xcd(c->nelemd) * nqc);
+  // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: qsize*72 (+ 72) always is
+  if (Qn0_avg)
+    hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                       Qn0_avg, c->recvbuf, nlyr_halo, c->order, (const double*)c->dp, c->qmin2, c->qmax2, c->tps);
+  else
+    hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
+                       (const double*)nullptr, c->recvbuf, nlyr_halo, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr, c->tps);
+  LAUNCH_CHECK();
   return 0;
 }
 
-// gor ("gather on read", whole-step path only): stages 1 and 2 leave their pre-DSS scratch (T, then B) un-DSS'd and the
-// next stage's slab kernel assembles rspheremp*DSS(.) while reading it; the stage-3 Laplacian is handed over the same way.
-static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused = false,
-                           bool fused_mm = false, bool gor = false) {
+// One euler_step of the per-stage API (prim_advection_mod.F90:667-970): every stage ends with a tracer DSS pass, because
+// Qdp(np1) must exist after each call; all work and the halo exchanges are ordered on the compute stream.
+static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused_mm) {
   if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
   double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
   double** var = DSSopt == 1 ? &c->eta : DSSopt == 2 ? &c->omega_p : DSSopt == 3 ? &c->divdp_proj : nullptr;
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
+  const int nq = c->qsize * NLEV;
   const dim3 grid(flat_blocks(c->nelemd)), blk(FLAT_THREADS);
+  const GatherArgs plain{nullptr, nullptr, c->tps, nullptr, c->nelemd};
   if (rhs == 0) {
     if (fused_mm && c->mm_valid == n0_qdp) {
       // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
@@ -541,93 +647,45 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance0");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, plain);
     LAUNCH_CHECK();
   } else if (rhs == 1) {
     Scope s(c, "advance1");
-    if (gor)   // input: stage 1's scratch T (with its halo columns), output: B
-      hipLaunchKernelGGL((k_advance<1, 1>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)c->T,
-                         (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                         GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
-    else
-      hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
-                         c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
-    LAUNCH_CHECK();
-  } else if (gor) {
-    const int nq = c->qsize * NLEV;
-    {   // input: stage 2's scratch B (+ halo); outputs: Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, qmin/qmax
-      Scope s(c, "lap");
-      hipLaunchKernelGGL(k_lap1<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, (const double*)c->B, c->T, c->dp,
-                         c->divdp_proj, c->qmin, c->qmax, Qnp1, GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
-      LAUNCH_CHECK();
-    }
-    if (neighbor_minmax(c)) return 1;   // before the Laplacian's halo exchange: k_advance reads that one out of recvbuf
-    if (c->ncol_send) {
-      size_t tot = (size_t)c->ncol_send * nq;
-      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->T,
-                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps, 0);
-      LAUNCH_CHECK();
-    }
-    if (halo_exchange(c, nq)) return 1;
-    if (unpack_halo(c, c->T, nq)) return 1;
-    Scope s(c, "advance2");
-    hipLaunchKernelGGL((k_advance<2, 2>), grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, (const double*)Qnp1,
-                       (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                       GatherArgs{c->dss_tab, c->rspheremp, c->tps, slab_order(c)});
+    hipLaunchKernelGGL(k_advance<1>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
+                       c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, plain);
     LAUNCH_CHECK();
   } else {
     c->t_zero_dirty = true;   // below, T receives rspheremp*DSS(lap) in the plain tracer layout
-    if (!fused) {   // in the fused whole-step path the stage-2 DSS (k_dss_t<3>) has already produced B, qmin, qmax
+    {
       Scope s(c, "lap");
       hipLaunchKernelGGL(k_lap1<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax,
-                         (double*)nullptr, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
+                         (double*)nullptr, plain);
       LAUNCH_CHECK();
     }
-    // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1)
-    const int nq = c->qsize * NLEV;
-    if (c->ncol_send) {
-      // message layout of edgeAdvQ3 is (lap, Qmin, Qmax) = 3*qsize*nlev layers (viscosity_mod.F90:389-391); we send the
-      // Laplacian and the bounds as two exchanges of the sizes the halo buffer is dimensioned for
-      size_t tot = (size_t)c->ncol_send * nq;
-      hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->ncol_send, nq, c->send_src, c->B,
-                         (const double*)nullptr, c->sendbuf, nq, 0, c->tps, 0);
-      LAUNCH_CHECK();
-    }
-    if (halo_exchange(c, nq)) return 1;
-    {
-      Scope s(c, "dss");
-      const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-      const dim3 g2(8 * dss_blocks_per_xcd<NLEV * 4>(c->nelemd) * nqc);
-      if (fused) {  // DSS + inverse mass + second Laplacian + biharmonic scaling in one pass: T = biharmonic term
-        DssExtra X{}; X.D = c->D; X.G = c->geo(); X.dt = dt; X.nu_q = c->nu_q; X.dp0 = c->dp0; X.tps = c->tps;
-        hipLaunchKernelGGL(k_dss_t<2>, g2, dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, c->B, c->T,
-                           (const double*)nullptr, c->recvbuf, nq, X, c->order);
-      } else {
-        hipLaunchKernelGGL(k_dss_t2<0>, dim3(8 * dss2_blocks_per_xcd(c->nelemd) * nqc), dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab,
-                           c->rspheremp, c->B, c->T, (const double*)nullptr, c->recvbuf, nq, c->order, (const double*)nullptr, (double*)nullptr,
-                           (double*)nullptr, c->tps);
-      }
-      LAUNCH_CHECK();
-    }
+    // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1).  The reference's message is
+    // (lap, Qmin, Qmax) = 3*qsize*nlev layers (viscosity_mod.F90:389-391); here the Laplacian and the bounds travel separately.
+    if (pack_tracers(c, c->stream, c->B, nq)) return 1;
+    if (halo_exchange(c, nq, 0, c->stream)) return 1;
+    if (dss_tracer_pass(c, c->B, c->T, nullptr, nq)) return 1;
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance2");
-    if (fused)
-      hipLaunchKernelGGL(k_advance<3>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
-    else
-      hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
-                         c->divdp_proj, c->qmin, c->qmax, c->dp0, GatherArgs{nullptr, nullptr, c->tps, slab_order(c)});
+    hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
+                       c->divdp_proj, c->qmin, c->qmax, c->dp0, plain);
     LAUNCH_CHECK();
   }
-  const double* pre = (rhs == 2 || (gor && rhs == 1)) ? c->B : c->T;
+  const double* pre = rhs == 2 ? c->B : c->T;
   const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
-  // fused path: the stage-2 DSS also forms Q = Qdp/dp for stage 3 (dp uses rhs_multiplier 2 and the stage dt)
-  return dss_tracers_and_var(c, pre, Qnp1, var, var_levels, avg, fused && rhs == 1, 2 * dt, gor && rhs != 2);
+  // edgeVpack(Qdp) + edgeVpack(spheremp*DSSvar) -> bndry_exchangeV -> edgeVunpack + rspheremp  (:911-960)
+  if (pack_tracers(c, c->stream, pre, nq + NLEV)) return 1;
+  if (var && pack_var(c, c->stream, *var, var_levels)) return 1;
+  if (halo_exchange(c, nq + NLEV, 0, c->stream)) return 1;
+  if (dss_tracer_pass(c, pre, Qnp1, avg, nq + NLEV)) return 1;
+  return dss_level_var(c, var, var_levels);
 }
 
 int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
   c->mm_valid = 0;
-  return euler_step_impl(c, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier, false, 0);
+  return euler_step_impl(c, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier, false, 0, false);
 }
 
 int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
@@ -640,48 +698,175 @@ int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
   return 0;
 }
 
-int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) {
-  if (n0_qdp == np1_qdp) return fail("advec_tracers_remap_rk2: n0_qdp == np1_qdp");
-  if (tse_compute_divdp(c)) return 1;
-  const bool f = fuse_stage3();
-  const bool gor = !f && dss_on_read() && c->tps * 8 < ((size_t)1 << 32);   // gather offsets are 32-bit bytes within a plane
-  if (gor && c->t_zero_dirty) {   // restore the all-zero element of every plane of T
-    HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * TLEV, c->tps * 8, 0, (size_t)16 * TLEV * 8, c->qsize, c->stream));
-    c->t_zero_dirty = false;
+// ---- whole-step path: DSS on read + boundary-first overlap ------------------------------------------
+// Stages 1 and 2 leave their pre-DSS scratch (T, then B) un-DSS'd and the next stage's slab kernel assembles
+// rspheremp*DSS(.) while reading it; the stage-3 Laplacian is handed over the same way.
+//
+// On several ranks every slab kernel is launched twice: over the elements that touch another rank (`ord_bnd`), then over
+// the rest (`ord_int`).  Between the two launches the communication stream is handed the pack -> exchange -> unpack of
+// the stage, so the halo travels over xGMI while the interior elements are computed; the compute stream waits for it
+// only before the next stage's first launch.  With an RCCL communicator nothing blocks the host.  With the callback
+// form of the seam the host has to drain the packs and run the callback; that is done after the interior launch has
+// been queued, so the overlap is kept there too.
+static hipEvent_t next_sync_event(tse_ctx* c) {
+  hipEvent_t e = c->sync_events[c->sync_next];
+  c->sync_next = (c->sync_next + 1) % c->sync_events.size();
+  return e;
+}
+
+template <class Launch, class CommWork>
+static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (order, nwork) */, CommWork comm_work /* () on c->comm_stream */) {
+  Scope s(c, timer);
+  if (!c->halo()) return launch((const int*)nullptr, c->nelemd);
+  if (launch((const int*)c->ord_bnd, c->n_bnd)) return 1;
+  hipEvent_t evB = next_sync_event(c), evC = next_sync_event(c);
+  HIPCHK(hipEventRecord(evB, c->stream));
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, evB, 0));
+  if (c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
+  if (c->n_int && launch((const int*)c->ord_int, c->n_int)) return 1;
+  if (!c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
+  HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
+  return 0;
+}
+
+static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp) {
+  double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
+  double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  const int nq = c->qsize * NLEV;
+  const dim3 blk(FLAT_THREADS);
+  hipStream_t cs = c->comm_stream;
+  auto plain = [&](const int* ord, int nw) { return GatherArgs{nullptr, nullptr, c->tps, ord, nw}; };
+  auto gath = [&](const int* ord, int nw) { return GatherArgs{c->dss_tab, c->rspheremp, c->tps, ord, nw}; };
+
+  // ---- stage 1 (rhs_multiplier 0, DSS extra = divdp_proj): bounds, neighbour min/max, advance Qdp(n0) -> T
+  if (c->mm_valid == n0_qdp) {
+    // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
+    std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
+  } else {
+    Scope s(c, "minmax");
+    hipLaunchKernelGGL(k_qminmax, dim3(flat_blocks(c->nelemd)), blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
+    LAUNCH_CHECK();
   }
-  if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, f, true, gor)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, f, false, gor)) return 1;
-  if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, f, false, gor)) return 1;
+  c->mm_valid = 0;
+  {   // the min/max halo travels under divdp = div(vn0)
+    auto mm_comm = [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs); };
+    hipEvent_t ev0 = nullptr, evM = nullptr;
+    if (c->halo()) {
+      ev0 = next_sync_event(c); evM = next_sync_event(c);
+      HIPCHK(hipEventRecord(ev0, c->stream));
+      HIPCHK(hipStreamWaitEvent(cs, ev0, 0));
+      if (c->comm) { if (mm_comm()) return 1; HIPCHK(hipEventRecord(evM, cs)); }
+    }
+    if (tse_compute_divdp(c)) return 1;
+    if (c->halo()) {
+      if (!c->comm) { if (mm_comm()) return 1; HIPCHK(hipEventRecord(evM, cs)); }
+      HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
+    }
+    if (nbr_minmax_kernel(c)) return 1;
+  }
+  if (split_stage(c, "advance0",
+        [&](const int* ord, int nw) -> int {
+          hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qn0,
+                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, plain(ord, nw));
+          LAUNCH_CHECK(); return 0; },
+        [&]() -> int { return pack_tracers(c, cs, c->T, nq + NLEV) || pack_var(c, cs, c->divdp_proj, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
+                              unpack_halo(c, cs, c->T, nq + NLEV); })) return 1;
+  if (dss_level_var(c, &c->divdp_proj, NLEV)) return 1;
+
+  // ---- stage 2 (rhs_multiplier 1, DSS extra = eta_dot_dpdn): T (+) edges -> B
+  if (split_stage(c, "advance1",
+        [&](const int* ord, int nw) -> int {
+          hipLaunchKernelGGL((k_advance<1, 1>), dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->T,
+                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gath(ord, nw));
+          LAUNCH_CHECK(); return 0; },
+        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->eta, NLEVP) || halo_exchange(c, nq + NLEV, 0, cs) ||
+                              unpack_halo(c, cs, c->B, nq + NLEV); })) return 1;
+  if (dss_level_var(c, &c->eta, NLEVP)) return 1;
+
+  // ---- stage 3 (rhs_multiplier 2, DSS extra = omega_p)
+  // 3a: B (+) edges -> Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, element min/max; the bounds and the
+  //     Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
+  if (split_stage(c, "lap",
+        [&](const int* ord, int nw) -> int {
+          hipLaunchKernelGGL(k_lap1<1>, dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
+                             c->divdp_proj, c->qmin, c->qmax, Qnp1, gath(ord, nw));
+          LAUNCH_CHECK(); return 0; },
+        [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
+                              unpack_halo(c, cs, c->T, nq); })) return 1;
+  if (nbr_minmax_kernel(c)) return 1;
+  // 3b: Qdp(np1), T (+) edges -> B (2nd Laplacian + biharmonic scaling + advance + limiter)
+  if (split_stage(c, "advance2",
+        [&](const int* ord, int nw) -> int {
+          hipLaunchKernelGGL((k_advance<2, 2>), dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qnp1,
+                             (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gath(ord, nw));
+          LAUNCH_CHECK(); return 0; },
+        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs); })) return 1;
+  // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
+  if (dss_tracer_pass(c, c->B, Qnp1, Qn0, nq + NLEV)) return 1;
+  return dss_level_var(c, &c->omega_p, NLEV);
+}
+
+int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) {
+  if (n0_qdp == np1_qdp || n0_qdp < 1 || n0_qdp > 2 || np1_qdp < 1 || np1_qdp > 2)
+    return fail("advec_tracers_remap_rk2: time levels n0_qdp=%d np1_qdp=%d", n0_qdp, np1_qdp);
+  bool gor = dss_on_read();
+  if (gor && c->tps * 8 >= ((size_t)1 << 32)) {   // gather offsets are 32-bit bytes within a plane
+    static bool said = false;
+    if (!said) {
+      fprintf(stderr, "transport_se_hip: a scratch plane is %zu bytes (>= 4 GiB): DSS on read disabled, one DSS pass per stage\n", c->tps * 8);
+      said = true;
+    }
+    gor = false;
+  }
+  if (gor) {
+    if (c->t_zero_dirty) {   // restore the all-zero element of every plane of T
+      HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * TLEV, c->tps * 8, 0, (size_t)16 * TLEV * 8, c->qsize, c->stream));
+      c->t_zero_dirty = false;
+    }
+    if (advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp)) return 1;
+  } else {
+    if (tse_compute_divdp(c)) return 1;
+    if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, true)) return 1;
+    if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, false)) return 1;
+    if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, false)) return 1;
+  }
   c->mm_valid = np1_qdp;   // the final DSS emitted min/max of Qdp(np1)/dp for the next step
   return 0;
 }
 
-int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
+static int remap_launch(tse_ctx* c, double dt, int np1_qdp) {
   if (np1_qdp < 1 || np1_qdp > 2) return fail("vertical_remap: np1_qdp=%d", np1_qdp);
-  {
-    Scope s(c, "remap");
-    // TSE_REMAP_NT: tracers per thread in the lockstep column loop; TSE_REMAP_GENERIC=1: always take the generic loop (tests)
-    const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
-    const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
-    double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
-    if (nt == 1)
-      hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
-    else
-      hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
-    LAUNCH_CHECK();
-  }
+  Scope s(c, "remap");
+  // TSE_REMAP_NT: tracers per thread in the lockstep column loop; TSE_REMAP_GENERIC=1: always take the generic loop (tests)
+  const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
+  const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
+  double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  if (nt == 1)
+    hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
+  else
+    hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
+  LAUNCH_CHECK();
+  c->mm_valid = np1_qdp;   // k_remap emitted the element min/max of the remapped field
+  return 0;
+}
+// the reference's abort condition (prim_advection_mod.F90:1323): the device flag every remap since the last check ORs into
+static int remap_check(tse_ctx* c) {
   int bad = 0;
   HIPCHK(hipMemcpyAsync(&bad, c->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
-  c->mm_valid = bad ? 0 : np1_qdp;   // k_remap emitted the element min/max of the remapped field
   if (bad) {
+    c->mm_valid = 0;
     HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
     fail("negative layer thickness.  timestep or remap time too large");
     return 2;
   }
   return 0;
+}
+int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
+  if (remap_launch(c, dt, np1_qdp)) return 1;
+  return remap_check(c);
 }
 
 // ---- prescribed fields + device-resident driver ---------------------------------------------------
@@ -701,6 +886,7 @@ int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, c
   std::vector<double> la(lat, lat + (size_t)c->nelemd * 16), lo(lon, lon + (size_t)c->nelemd * 16);
   void* old[] = {c->lat, c->lon, c->zm, c->zi, c->pint, c->dph};
   for (void* p : old) if (p) (void)hipFree(p);
+  c->lat = c->lon = c->zm = c->zi = c->pint = c->dph = nullptr;
   if (upload(&c->lat, la) || upload(&c->lon, lo) || upload(&c->zm, zm) || upload(&c->zi, zi) || upload(&c->pint, pint) || upload(&c->dph, dph)) return 1;
   if (!c->dcmip_tab && dalloc(&c->dcmip_tab, 1)) return 1;
   hipLaunchKernelGGL(k_dcmip_tables, dim3(1), dim3(128), 0, c->stream, test, c->zm, c->zi, c->dcmip_tab);   // level-only factors
@@ -722,6 +908,8 @@ int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
   Scope s(c, "dcmip");
   size_t tot = (size_t)c->nelemd * 16;   // one thread per column
   double t_wind = (nstep > 0 ? nstep - 1 : 0) * tstep, t_now = nstep * tstep;
+  // derived%dp is rewritten with the same time-independent p_i(k+1) - p_i(k) on every step (dcmip_wrapper_mod.F90:183,199), so
+  // the cached next-step bounds (formed with that dp) stay valid; every other writer of dp drops them (tse_set_derived)
   hipLaunchKernelGGL(k_dcmip_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
                      c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dp, c->eta, c->omega_p);
   LAUNCH_CHECK();
@@ -737,23 +925,25 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
       if (tse_advec_tracers_remap_rk2(c, tstep, n0, np1)) return 1;
       nstep++;
     }
-    int rc = tse_vertical_remap(c, tstep * c->rsplit, np1);
-    if (rc) { *nstep_io = nstep; return rc; }
+    if (remap_launch(c, tstep * c->rsplit, np1)) { *nstep_io = nstep; return 1; }
   }
   *nstep_io = nstep;
-  return 0;
+  // the negative-thickness flag of all nsub remaps is read once: the loop above never blocks the host
+  return remap_check(c);
 }
 
 // ---- introspection ------------------------------------------------------------------------------
 void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   struct Ent { const char* n; void* p; size_t b; };
-  const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8;
-  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, trc}, {"B", c->B, trc}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
+  const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8, scr = (size_t)c->qsize * c->tps * 8;
+  const size_t m2 = (size_t)2 * c->qsize * NLEV * 8;
+  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr}, {"B", c->B, scr}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
                 {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
                 {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},
                 {"qmax", c->qmax, mm}, {"sendbuf", c->sendbuf, (size_t)c->ncol_send * c->nlyr_halo * 8},
-                {"recvbuf", c->recvbuf, (size_t)c->ncol_recv * c->nlyr_halo * 8}};
-  for (auto& e : ents) if (!strcmp(e.n, name)) { if (nbytes) *nbytes = e.b; return e.p; }
+                {"recvbuf", c->recvbuf, (size_t)c->ncol_recv * c->nlyr_halo * 8}, {"sendbuf_mm", c->sendbuf_mm, (size_t)c->nmm_send * m2},
+                {"recvbuf_mm", c->recvbuf_mm, (size_t)c->nmm_recv * m2}};
+  for (auto& e : ents) if (!strcmp(e.n, name)) { if (nbytes) *nbytes = e.p ? e.b : 0; return e.p; }
   if (nbytes) *nbytes = 0;
   return nullptr;
 }
@@ -764,7 +954,8 @@ int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {
   const size_t len = strlen(name);
   for (auto& kv : c->timers)   // prefix match: "advance" = advance0 + advance1 + advance2
     if (kv.first.compare(0, len, name) == 0) { t += kv.second.ms; n += kv.second.n; }
-  if (ms) *ms = t; if (launches) *launches = n;
+  if (ms) *ms = t;
+  if (launches) *launches = n;
   return 0;
 }
 

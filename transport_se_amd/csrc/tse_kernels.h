@@ -144,7 +144,10 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 // own points plus up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges,
 // then the corner) and the same inverse-mass multiply as k_dss_t2, so the value is bit-identical to what the DSS pass would
 // have stored.  That removes one read+write pass over the tracers per fused hand-over.
-struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const int* order; };
+// order/nwork: the element slots this launch walks -- order[0..nwork) (nullptr: elements 0..nwork).  A multi-rank step
+// launches every slab kernel twice: first over the elements that touch another rank, so that their halo can travel while
+// the second launch computes the interior elements (tse_api.hip).
+struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const int* order; int nwork; };
 // Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
 // per-load address arithmetic).  An empty table slot points into the all-zero element behind the local ones, a remote slot
 // into the halo columns that k_unpack_halo copied behind that, so all loads are unconditional and alike.
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
-  const SlabId sid = flat_slab(nelemd, GA.order);
+  const SlabId sid = flat_slab(GA.nwork, GA.order);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      dpk[i] = dpk[i] - (RHS == 3 ? 2 : RHS) * dt * t0[i];
+      dpk[i] = dpk[i] - RHS * dt * t0[i];
       dps[i] = dpk[i] - dt * t1[i];
       rdps[i] = 1.0 / dps[i];
       rdpk[i] = 1.0 / dpk[i];
@@ -298,7 +301,6 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
     if (RHS == 2) make_lap_geo(L, g);
   }
-  // RHS == 3: stage 3 (rhs_multiplier 2) with the biharmonic term already formed by k_dss_t<2> in `lap`
   const double sumc = quad_sum(((c[0] + c[1]) + c[2]) + c[3]);
   double visc[4];
 #pragma unroll
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = ((size_t)e * qsize + q) * NLEV + kc;
     if (GIN) gather_issue(RG, GA, gsrc, q, graw);
     if (GIN != 1) load4(Qn0 + so, qnx);
-    if (RHS == 3 || (RHS == 2 && GIN != 2)) load4(lap + so, lsx);
+    if (RHS == 2 && GIN != 2) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
   };
   if (GIN) gather_setup(RG, GA, nelemd, e, j, kc);
@@ -389,10 +391,6 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 #pragma unroll
       for (int i = 0; i < 4; i++) x[i] = x[i] + bih[i];
     }
-    if (RHS == 3) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = x[i] + ls[i];
-    }
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
     changed |= limiter8_quad(x, c, sumc, minp, maxp);
@@ -423,7 +421,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax, double* __restrict__ Qout,
                                                        GatherArgs GA) {
-  const SlabId sid = flat_slab(nelemd, GA.order);
+  const SlabId sid = flat_slab(GA.nwork, GA.order);
   const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
   LapGeo L;
   {
@@ -500,18 +498,6 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 // Work items are ordered tracer-chunk-major and the 8 XCDs each walk a contiguous range of elements (see k_dss).
 // MODE 0: dst = rspheremp * DSS(src)                                   (prim_advection_mod.F90:929-960)
 // MODE 1: ... fused with qdp_time_avg: dst = (Qn0 + 2*that)/3         (:645-662)
-// MODE 2: src = first Laplacian: dst = -3 dt nu_q dp0(k) * laplace_sphere_wk(rspheremp*DSS(src)) / spheremp, the
-//         biharmonic term euler_step adds in stage 3 (viscosity_mod.F90:419-423, prim_advection_mod.F90:813-826)
-// MODE 3: stage-2 DSS that also starts stage 3: dst = Qdp(np1) as MODE 0, plus Q = Qdp/dp (dp = derived%dp -
-//         2 dt divdp_proj), element min/max -> qmin/qmax, first Laplacian -> lapout in the level-fastest layout
-//         (prim_advection_mod.F90:750-761,796-809, viscosity_mod.F90:378-389)
-struct DssExtra {
-  Dvv_t D; GeoPtrs G;
-  double dt, nu_q;                 // MODE 2: stage dt ; MODE 3: rdt = 2*dt in `dt`
-  const double* dp0;               // MODE 2
-  const double* dp; const double* divdp_proj; double* qmin; double* qmax; double* lapout;   // MODE 3
-  size_t tps;                      // plane stride of the scratch layout (all modes)
-};
 // Lane mapping shared by the tracer DSS kernels: work = (tracer chunk, XCD range of elements, flattened (element slot,
 // unit)) with UNITS lanes per element.  288 (or 144) lanes per element do not fill whole waves, so the lanes of a block run
 // across element boundaries: no idle lanes except in a range's last block, and blocks of 4 waves instead of 5.
@@ -529,109 +515,13 @@ __device__ __forceinline__ DssLane dss_lane(int nelemd) {
   l.qc = it / B8; l.r = g - idx * UNITS; l.slot = xcd * S8 + idx; l.live = idx < S8 && l.slot < nelemd;
   return l;
 }
-template <int MODE>
-__global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_t(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
-                                                            const double* __restrict__ rspheremp, const double* __restrict__ src,
-                                                            double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                            const double* __restrict__ recvbuf, int nlyr_halo, DssExtra X,
-                                                            const int* __restrict__ order) {
-  const DssLane ln = dss_lane<NLEV * 4>(nelemd);
-  if (!ln.live) return;
-  const int e = order[ln.slot];   // walk order inside the XCD's element range: neighbours close in time (tse_api.hip)
-  const int qc = ln.qc, k = ln.r >> 2, j = ln.r & 3, kc = k;
-  // Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take up to 3 contributions
-  // (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot re-reads the
-  // lane's own value and is weighted 0) so that the 8 loads are in flight together -- a load inside a divergent
-  // branch is waited for on the spot, which serialises 8 memory latencies per tracer.
-  constexpr int NS = 8;
-  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
-  const double* gp[NS];   // address of the contribution for tracer q0, level kc
-  unsigned gvalid = 0, gremote = 0;   // bit s: slot populated / comes from the halo buffer (tracer stride NLEV)
-  const int q0 = qc * qb;
-  const double* own0 = src + t_idx(X.tps, q0, e, j * 4, kc);
-  int2 tt[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];   // 8 loads in flight together
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const int2 t = tt[s];
-    if (t.x >= 0) { gp[s] = src + t_idx(X.tps, q0, t.x, t.y, kc); gvalid |= 1u << s; }
-    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + kc; gvalid |= 1u << s; gremote |= 1u << s; }
-    else gp[s] = own0;
-  }
-  double rs[4];
-  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
-  LapGeo L;
-  double visc[4] = {0, 0, 0, 0}, rdpk[4] = {0, 0, 0, 0};
-  if (MODE == 2 || MODE == 3) {
-    RowGeo g;
-    load_row_geo(g, X.G.dvv, X.G.Dinv, X.G.metdet, X.G.rmetdet, X.G.spheremp, e, j);
-    make_lap_geo(L, g);
-    if (MODE == 2) {
-#pragma unroll
-      for (int i = 0; i < 4; i++) visc[i] = (-3.0 * X.dt * X.nu_q * X.dp0[kc]) / g.spheremp[i];
-    }
-  }
-  if (MODE == 3) {
-    double d0[4], d1[4];
-    load4(X.dp + ((size_t)e * NLEV + kc) * 16 + j * 4, d0); load4(X.divdp_proj + ((size_t)e * NLEV + kc) * 16 + j * 4, d1);
-#pragma unroll
-    for (int i = 0; i < 4; i++) rdpk[i] = 1.0 / (d0[i] - X.dt * d1[i]);
-  }
-  const int q1 = min(qsize, (qc + 1) * qb);
-  for (int q = q0; q < q1; q++) {
-    const size_t dq = (size_t)(q - q0);
-    double v[4], a[NS];
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = own0[dq * X.tps + (size_t)i * TLEV];
-#pragma unroll
-    for (int s = 0; s < NS; s++) a[s] = 0.0;
-    // loads only (predicated per lane); every use comes after the last load so that no wait lands between them
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-      if (gvalid & (1u << s)) a[s] = gp[s][dq * ((gremote & (1u << s)) ? (size_t)NLEV : X.tps)];
-    // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
-    v[0] = v[0] + a[0]; v[0] = v[0] + a[1]; v[0] = v[0] + a[2];
-    v[1] = v[1] + a[3];
-    v[2] = v[2] + a[4];
-    v[3] = v[3] + a[5]; v[3] = v[3] + a[6]; v[3] = v[3] + a[7];
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = rs[i] * v[i];
-    const size_t off = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
-    if (MODE == 1) {
-      double q0v[4];
-      load4(Qn0 + off, q0v);
-#pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = (q0v[i] + 2 * v[i]) / 3;  // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
-    }
-    if (MODE == 2) {
-      double l2[4];
-      laplace_lean_row(X.D, L, v, l2);
-#pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = visc[i] * l2[i];
-    }
-    if (k < NLEV) store4(dst + off, v);
-    if (MODE == 3) {
-      double x[4], l1[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = v[i] * rdpk[i];
-      double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
-      double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
-      laplace_lean_row(X.D, L, x, l1);
-      if (k < NLEV) {
-        double* bp = X.lapout + t_idx(X.tps, q, e, j * 4, k);
-#pragma unroll
-        for (int i = 0; i < 4; i++) bp[(size_t)i * TLEV] = l1[i];
-        if (j == 0) { X.qmin[((size_t)e * qsize + q) * NLEV + k] = mn; X.qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
-      }
-    }
-  }
-}
-
-// Default tracer DSS: as k_dss_t<0|1>, but every lane handles TWO consecutive levels, so that each own/neighbour access is
-// a 16-byte load (the level-fastest source makes the level pair contiguous).  The 8-byte version spent as much time
-// issuing the 12 loads per tracer as moving the data (a variant whose gathers all hit the lane's own element in L1 was
-// as slow as the real one).
+// Tracer DSS pass: every lane handles TWO consecutive levels of one row, so that each own/neighbour access is a 16-byte
+// load (the level-fastest source makes the level pair contiguous).  A one-level-per-lane version spent as much time
+// issuing its 12 eight-byte loads per tracer as moving the data (a variant whose gathers all hit the lane's own element
+// in L1 was as slow as the real one).  Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take
+// up to 3 contributions (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot
+// re-reads the lane's own value and is weighted 0) so that the 8 loads are in flight together -- a load inside a
+// divergent branch is waited for on the spot, which serialises 8 memory latencies per tracer.
 constexpr int DSS2_THREADS = DSS_FLAT_THREADS;
 constexpr int DSS2_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs x 4 rows
 inline int dss2_blocks_per_xcd(int nelemd) { return dss_blocks_per_xcd<DSS2_UNITS>(nelemd); }

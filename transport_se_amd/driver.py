@@ -3,8 +3,10 @@
 Mirrors prim_run_subcycle / prim_step (reference src/share/prim_driver_mod.F90:701-943) and TimeLevel_Qdp
 (time_mod.F90:85-109): rsplit tracer steps, each preceded by the prescribed-field refresh of prim_advance_exp
 (prim_advance_mod.F90:110-149), then vertical_remap.  One process per GPU; for world_size > 1 the elements are
-cut into contiguous chunks of the reference's space-filling curve and the DSS halo goes through torch.distributed
-(backend nccl == RCCL over xGMI) inside the exchange callback of the C ABI (the bndry_exchangeV seam).
+cut into contiguous chunks of the reference's space-filling curve and the DSS halo is exchanged INSIDE the library
+with RCCL send/recv over xGMI (tse_comm_init; the communicator id travels over torch.distributed, which is only the
+control plane here).  `exchange="torch"` / `"staged"` select the callback form of the seam instead (torch.distributed
+P2P ops on the device buffers, or host-staged slots for rehearsals where several ranks share one GPU).
 """
 import numpy as np
 
@@ -89,9 +91,31 @@ class HaloExchange:
         return 0
 
 
+def check_schedules_match(sched, minmax_len, rank, dist_mod):
+    """every rank's slot list must mirror its peers' (same peer set, same entry counts for both exchange kinds): a
+    mismatch would leave the grouped send/recv of some rank waiting forever, so it is caught here, on the control plane."""
+    mine = dict(send=[(int(p), int(l), int(m)) for (p, _, l), m in zip(sched["send"], minmax_len[0])],
+                recv=[(int(p), int(l), int(m)) for (p, _, l), m in zip(sched["recv"], minmax_len[1])])
+    world = dist_mod.get_world_size()
+    everyone = [None] * world
+    dist_mod.all_gather_object(everyone, mine)
+    for peer, ln, mm in mine["send"]:
+        theirs = [x for x in everyone[peer]["recv"] if x[0] == rank]
+        if theirs != [(rank, ln, mm)]:
+            raise RuntimeError("halo schedule mismatch: rank %d sends (%d cols, %d min/max entries) to rank %d, which expects %s"
+                               % (rank, ln, mm, peer, theirs))
+    for peer, ln, mm in mine["recv"]:
+        theirs = [x for x in everyone[peer]["send"] if x[0] == rank]
+        if theirs != [(rank, ln, mm)]:
+            raise RuntimeError("halo schedule mismatch: rank %d expects (%d cols, %d min/max entries) from rank %d, which sends %s"
+                               % (rank, ln, mm, peer, theirs))
+
+
 class PrimRun:
     def __init__(self, ne, qsize, test_case=1, nu_q=None, tstep=None, rsplit=3, rank=0, world=1, device=0,
-                 dist_mod=None, torch_mod=None, stage_through_host=False):
+                 dist_mod=None, torch_mod=None, exchange="rccl"):
+        """exchange (world > 1): "rccl" = in-library RCCL send/recv (production), "torch" = torch.distributed P2P ops in the
+        exchange callback, "staged" = callback with host-staged slots over a CPU backend (ranks may share a GPU)."""
         self.ne, self.qsize, self.rsplit, self.test_case = ne, qsize, rsplit, test_case
         self.nu_q = NU_Q.get(ne, 1e15 * (30.0 / ne) ** 3.2) if nu_q is None else nu_q
         self.tstep = TSTEP.get(ne, 300.0 * 30.0 / ne) if tstep is None else tstep
@@ -107,13 +131,23 @@ class PrimRun:
                          spheremp=geo["spheremp"][mine], rspheremp=geo["rspheremp"][mine],
                          putmapP=desc["putmapP"], getmapP=desc["getmapP"], reverse=desc["reverse"])
         self.lat, self.lon = geo["lat"][mine], geo["lon"][mine]
-        exchange = None
-        if world > 1:
-            exchange = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod, stage_through_host)
-        self._exchange = exchange
+        callback = None
+        if world > 1 and exchange != "rccl":
+            if exchange not in ("torch", "staged"):
+                raise ValueError("exchange=%r" % (exchange,))
+            callback = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod, stage_through_host=(exchange == "staged"))
+        self._exchange = callback
+        self.exchange_kind = exchange if world > 1 else "none"
         self.hip_device = device
+        self.rank, self.world = rank, world
         self.hip = HipMod(self.elem, cm.dvv(), (self.hv.hyai, self.hv.hybi, self.hv.ps0), qsize, self.nu_q,
-                          rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=exchange)
+                          rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=callback)
+        if world > 1:
+            check_schedules_match(desc, (self.hip.minmax_send_len, self.hip.minmax_recv_len), rank, dist_mod)
+            if exchange == "rccl":
+                box = [HipMod.comm_unique_id() if rank == 0 else None]
+                dist_mod.broadcast_object_list(box, src=0)
+                self.hip.comm_init(box[0], rank, world)
         self.hip.dcmip_init(test_case, self.lat, self.lon, self.hv.hyam, self.hv.hybm)
         self.hip.dcmip_set_initial()
         self.nstep = 0
@@ -130,7 +164,15 @@ class PrimRun:
         return 3 - n0
 
     def run(self, nsteps):
+        """nsteps prim_steps; whole rsplit cycles go through the device-resident loop (no host synchronisation inside)"""
         np1 = 2
+        while nsteps > 0 and self.nstep % self.rsplit:
+            np1 = self.step(); nsteps -= 1
+        ncyc = nsteps // self.rsplit
+        if ncyc:
+            self.nstep = self.hip.prim_run_subcycle(self.tstep, ncyc, self.nstep)
+            nsteps -= ncyc * self.rsplit
+            np1 = 2 if (self.nstep - 1) % 2 == 0 else 1        # the last step wrote 3 - n0, n0 = 1 + mod(nstep, 2)
         for _ in range(nsteps):
             np1 = self.step()
         return np1
