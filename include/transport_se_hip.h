@@ -132,6 +132,17 @@ int tse_vertical_remap(tse_ctx *ctx, double dt, int np1_qdp);
  * Qdp or dp drops the cache; a caller that writes state through tse_device_ptr must call this itself. */
 int tse_invalidate_cache(tse_ctx *ctx);
 
+/* Single calls of the public routines the path is built from, on host arrays (one call covers every local element):
+ *   divergence_sphere(v,deriv,elem)        derivative_mod.F90:2364-2414   v[ie][2][np*np] -> div[ie][np*np]
+ *   laplace_sphere_wk(s,deriv,elem,.true.) derivative_mod.F90:2418-2460   s[ie][np*np]    -> lap[ie][np*np]
+ *   remap_Q_ppm(Qdp,np,qsize,dp1,dp2)      prim_advection_mod.F90:98-214  Qdp[ie][qsize][nlev][np*np] in place,
+ *                                                                          dp1, dp2[ie][nlev][np*np]
+ * They run the same device routines as the fused kernels (operator-level parity checks; not used by the time loop;
+ * tse_remap_q_ppm overwrites time level 1 of the device tracer state and the dp/divdp_proj/dp3d level fields). */
+int tse_divergence_sphere(tse_ctx *ctx, const double *v, double *div);
+int tse_laplace_sphere_wk(tse_ctx *ctx, const double *s, double *lap);
+int tse_remap_q_ppm(tse_ctx *ctx, double *Qdp, const double *dp1, const double *dp2);
+
 /* qmin/qmax(nlev,qsize,nelemd) module state of prim_advection_mod (:459), for inspection: out[ie][q][k] */
 int tse_get_qminmax(tse_ctx *ctx, double *qmin, double *qmax);
 

@@ -78,15 +78,18 @@ def test_ne30_norms_match_readme(name):
 
 
 # README:149-151 "Updated 2015-11-27 (rsplit=3, ACME 72 level config)": run_ne120_tests.sh = ne120, tstep 75, nu_q 1e13, qsize 4.
-# 12 model days take 6 minutes on one MI355X, so this one only runs on request; its recorded output is
-# profiles/r01_ne120_q4_dcmip1-*_prim_main.txt (all printed digits of both lines, q_min included, are reproduced).
+# The 1-day DCMIP 1-2 line (1152 steps, about half a minute on one MI355X) always runs: it pins the headline resolution
+# against a line the reference's authors published.  The 12-day DCMIP 1-1 line takes 5-6 minutes, so it runs on request
+# (TSE_LONG_TESTS=1); its recorded output is profiles/r01_ne120_q4_dcmip1-*_prim_main.txt (all printed digits of both
+# lines, q_min included, are reproduced).
 README_NE120 = {"dcmip1-1": dict(L1=0.479398, L2=0.782613, Linf=0.922696, q_max=0.501561, test=1, tracer=1, nsteps=13824),
                 "dcmip1-2": dict(L1=0.081287, L2=0.264887, Linf=0.591157, q_max=0.959530, test=2, tracer=2, nsteps=1152)}
 
 
-@pytest.mark.skipif(os.environ.get("TSE_LONG_TESTS") != "1", reason="6 GPU-minutes: set TSE_LONG_TESTS=1")
 @pytest.mark.parametrize("name", ["dcmip1-2", "dcmip1-1"])
 def test_ne120_norms_match_readme(name):
+    if name == "dcmip1-1" and os.environ.get("TSE_LONG_TESTS") != "1":
+        pytest.skip("6 GPU-minutes: set TSE_LONG_TESTS=1")
     ref = README_NE120[name]
     run = PrimRun(120, 4, test_case=ref["test"], nu_q=1e13, tstep=75.0)
     q0 = run.fetch_qdp(1)[:, ref["tracer"] - 1].copy()

@@ -1,0 +1,62 @@
+"""-m gpu: single calls of the HIP operators against the REFERENCE's own single-call outputs (tests/golden/ref_ops.npz:
+divergence_sphere, laplace_sphere_wk -- derivative_mod.F90:2364,2418 -- and remap_Q_ppm -- prim_advection_mod.F90:98 --
+called by oracle/ref/ref_harness.F90 on LCG inputs), with the reference's own metric terms (ref_ne2_static.npz).
+Tolerances (fp64): the device routines contract a*b+c into FMAs and re-associate the metric products of the Laplacian
+(tse_device.h), so agreement is to a few ulp of the slab's largest term: 1e-14 (divergence), 5e-14 (Laplacian) relative to
+the slab maximum; remap: TOL_STEP = 5e-13 of the field maximum, column mass to 1e-13."""
+import numpy as np
+import pytest
+
+from transport_se_amd.hip_mod import HipMod
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref_ctx(gold):
+    st = gold("ref_ne2_static.npz")
+    elem = dict(Dinv=st["Dinv"], metdet=st["metdet"], rmetdet=st["rmetdet"], spheremp=st["spheremp"], rspheremp=st["rspheremp"],
+                putmapP=st["putmap"].astype(np.int32), getmapP=st["getmap"].astype(np.int32), reverse=st["reverse"].astype(np.int32))
+    hip = HipMod(elem, st["Dvv"], (st["hyai"], st["hybi"], float(st["ps0"])), 3, 1e19, device=0)
+    yield st, hip
+    hip.close()
+
+
+def test_divergence_sphere_single_call(ref_ctx, gold):
+    st, hip = ref_ctx
+    g = gold("ref_ops.npz")
+    v = np.zeros((hip.nelemd, 2, 4, 4))
+    for n, ie in enumerate(g["ie"]):
+        v[ie] = g["v"][n]
+    out = hip.divergence_sphere(v)
+    for n, ie in enumerate(g["ie"]):
+        ref = g["div"][n]
+        assert np.abs(out[ie] - ref).max() <= 1e-14 * np.abs(ref).max(), (ie, np.abs(out[ie] - ref).max() / np.abs(ref).max())
+    assert not out[len(g["ie"]):].any()          # zero flux -> zero divergence, exactly
+
+
+def test_laplace_sphere_wk_single_call(ref_ctx, gold):
+    st, hip = ref_ctx
+    g = gold("ref_ops.npz")
+    s = np.zeros((hip.nelemd, 4, 4))
+    for n, ie in enumerate(g["ie"]):
+        s[ie] = g["s"][n]
+    out = hip.laplace_sphere_wk(s)
+    for n, ie in enumerate(g["ie"]):
+        ref = g["lap_wk"][n]
+        assert np.abs(out[ie] - ref).max() <= 5e-14 * np.abs(ref).max(), (ie, np.abs(out[ie] - ref).max() / np.abs(ref).max())
+
+
+@pytest.mark.parametrize("generic", [0, 1])
+def test_remap_q_ppm_single_call(ref_ctx, gold, monkeypatch, generic):
+    """both reference cases (2 % and 20 % thickness perturbation) through the lockstep and the generic column loop"""
+    st, hip = ref_ctx
+    monkeypatch.setenv("TSE_REMAP_GENERIC", str(generic))
+    g = gold("ref_ops.npz")
+    n = hip.nelemd
+    which = np.arange(n) % 2                                        # the two fixture cases alternate over the elements
+    q = g["remap_Qin"][which]; dp1 = g["remap_dp1"][which]; dp2 = g["remap_dp2"][which]
+    out = hip.remap_q_ppm(q, dp1, dp2)
+    ref = g["remap_Qout"][which]
+    assert np.abs(out - ref).max() <= 5e-13 * np.abs(ref).max(), np.abs(out - ref).max() / np.abs(ref).max()
+    np.testing.assert_allclose(out.sum(2), q.sum(2), rtol=1e-13)    # column mass (pin(nlev+1) = pio(nlev+1), :144)

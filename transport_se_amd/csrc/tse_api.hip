@@ -843,10 +843,10 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp) {
   double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
   if (nt == 1)
     hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr);
   else
     hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink);
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr);
   LAUNCH_CHECK();
   c->mm_valid = np1_qdp;   // k_remap emitted the element min/max of the remapped field
   return 0;
@@ -867,6 +867,50 @@ static int remap_check(tse_ctx* c) {
 int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
   if (remap_launch(c, dt, np1_qdp)) return 1;
   return remap_check(c);
+}
+
+// ---- single calls of the public operators the path is built from (operator-level parity; host arrays in, host arrays out) ----
+template <int OP>
+static int elem_op(tse_ctx* c, const double* in, size_t in_per_elem, double* out) {
+  if (!in || !out) return fail("element operator: null argument");
+  double *din = nullptr, *dout = nullptr;
+  if (dalloc(&din, (size_t)c->nelemd * in_per_elem) || dalloc(&dout, (size_t)c->nelemd * 16)) { if (din) (void)hipFree(din); return 1; }
+  int rc = 0;
+  do {
+    if (hipMemcpyAsync(din, in, (size_t)c->nelemd * in_per_elem * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = fail("element operator: H2D copy failed"); break; }
+    hipLaunchKernelGGL(k_elem_op<OP>, dim3((c->nelemd * 4 + 255) / 256), dim3(256), 0, c->stream, c->nelemd, c->D, c->geo(), (const double*)din, dout);
+    if (hipGetLastError() != hipSuccess) { rc = fail("element operator: kernel launch failed"); break; }
+    if (hipMemcpyAsync(out, dout, (size_t)c->nelemd * 16 * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) { rc = fail("element operator: D2H copy failed"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { rc = fail("element operator: stream synchronisation failed"); break; }
+  } while (0);
+  (void)hipFree(din); (void)hipFree(dout);
+  return rc;
+}
+int tse_divergence_sphere(tse_ctx* c, const double* v, double* div) { return elem_op<0>(c, v, 32, div); }
+int tse_laplace_sphere_wk(tse_ctx* c, const double* s, double* lap) { return elem_op<1>(c, s, 16, lap); }
+
+// remap_Q_ppm(Qdp,np,qsize,dp1,dp2) (prim_advection_mod.F90:98-214) for every local element: the column kernel of
+// vertical_remap with the caller's source and target thicknesses.  Uses time level 1 of the device tracer state and the
+// level fields dp/divdp_proj/dp3d as work space (a test/utility call, not part of the time loop).
+int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp2) {
+  if (!Qdp || !dp1 || !dp2) return fail("tse_remap_q_ppm: null argument");
+  c->mm_valid = 0;
+  const size_t lev = c->lev();
+  double* d2 = nullptr;
+  if (dalloc(&d2, lev)) return 1;
+  int rc = 0;
+  do {
+    if (hipMemcpy(c->qdp, Qdp, c->trc() * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->dp, dp1, lev * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d2, dp2, lev * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->divdp_proj, 0, lev * 8) != hipSuccess) { rc = fail("tse_remap_q_ppm: upload failed"); break; }
+    const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
+    hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2);
+    if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(Qdp, c->qdp, c->trc() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("tse_remap_q_ppm: download failed"); break; }
+    rc = remap_check(c);
+  } while (0);
+  (void)hipFree(d2);
+  return rc;
 }
 
 // ---- prescribed fields + device-resident driver ---------------------------------------------------

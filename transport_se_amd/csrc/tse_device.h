@@ -110,38 +110,8 @@ __device__ __forceinline__ void divergence_sphere_row(const Dvv_t& D, const RowG
   for (int i = 0; i < 4; i++) div[i] = (dx[i] + dy[i]) * (g.rmetdet[i] * RREARTH);
 }
 
-// laplace_sphere_wk = divergence_sphere_wk(gradient_sphere(s))  (derivative_mod.F90:1660-1700,2027-2097,2418-2460)
-__device__ __forceinline__ void laplace_sphere_wk_row(const Dvv_t& D, const RowGeo& g, const double s[4], double lap[4]) {
-  double dx[4], dy[4], w1[4], w2[4];
-  deriv_xy(D, g, s, s, dx, dy);
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double v1 = dx[i] * RREARTH, v2 = dy[i] * RREARTH;
-    double ds1 = g.Di11[i] * v1 + g.Di21[i] * v2;   // gradient_sphere: Dinv^T
-    double ds2 = g.Di12[i] * v1 + g.Di22[i] * v2;
-    double vt1 = g.Di11[i] * ds1 + g.Di12[i] * ds2; // divergence_sphere_wk: latlon -> contra
-    double vt2 = g.Di21[i] * ds1 + g.Di22[i] * ds2;
-    w1[i] = g.spheremp[i] * vt1;
-    w2[i] = g.spheremp[i] * vt2;
-  }
-  // div(m,n) = - sum_j [ w1(j,n) Dvv(m,j) + w2(m,j) Dvv(n,j) ] * rrearth ; n = my row
-  double r0[4], r1[4], r2[4], r3[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    r0[i] = quad_bcast<0>(w2[i]); r1[i] = quad_bcast<1>(w2[i]); r2[i] = quad_bcast<2>(w2[i]); r3[i] = quad_bcast<3>(w2[i]);
-  }
-#pragma unroll
-  for (int m = 0; m < 4; m++) {
-    double d = 0.0;
-    d = d - (w1[0] * D.d[0 * 4 + m] + r0[m] * g.drow[0]) * RREARTH;
-    d = d - (w1[1] * D.d[1 * 4 + m] + r1[m] * g.drow[1]) * RREARTH;
-    d = d - (w1[2] * D.d[2 * 4 + m] + r2[m] * g.drow[2]) * RREARTH;
-    d = d - (w1[3] * D.d[3 * 4 + m] + r3[m] * g.drow[3]) * RREARTH;
-    lap[m] = d;
-  }
-}
-
-// Register-lean form of laplace_sphere_wk for the fused kernels: with v = rrearth*(ds/dx, ds/dy),
+// laplace_sphere_wk = divergence_sphere_wk(gradient_sphere(s))  (derivative_mod.F90:1660-1700,2027-2097,2418-2460) in a
+// register-lean form: with v = rrearth*(ds/dx, ds/dy),
 //   vtemp = Dinv * (Dinv^T v)  =  [A B; B C] v,  A = Di11^2+Di12^2, B = Di11*Di21+Di12*Di22, C = Di21^2+Di22^2
 // so only the 3 entries of the symmetric tensor spheremp*rrearth^2*[A B; B C] are kept per point (12 doubles per
 // lane instead of 20); same operator as derivative_mod.F90:2418-2460, products re-associated.

@@ -75,6 +75,31 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_divdp(int nelemd, Dvv_t D, Geo
   }
 }
 
+// Single calls of the element-local operators on one 4x4 slab per element (the public derivative_mod functions the path is
+// built from: divergence_sphere, derivative_mod.F90:2364-2414; laplace_sphere_wk, :2418-2460), through the same device
+// routines the fused kernels use.  thread = (element, row j); OP 0: out = divergence_sphere(in[e][2][16]),
+// OP 1: out = laplace_sphere_wk(in[e][16]).
+template <int OP>
+__global__ __launch_bounds__(256) void k_elem_op(int nelemd, Dvv_t D, GeoPtrs G, const double* __restrict__ in, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, j = t & 3;
+  const int e = min(t >> 2, nelemd - 1);   // whole quads stay active (the DPP moves need all four rows)
+  RowGeo g;
+  load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
+  double r[4];
+  if (OP == 0) {
+    double v1[4], v2[4];
+    load4(in + ((size_t)e * 2 + 0) * 16 + j * 4, v1); load4(in + ((size_t)e * 2 + 1) * 16 + j * 4, v2);
+    divergence_sphere_row(D, g, v1, v2, r);
+  } else {
+    double sv[4];
+    LapGeo L;
+    make_lap_geo(L, g);
+    load4(in + (size_t)e * 16 + j * 4, sv);
+    laplace_lean_row(D, L, sv, r);
+  }
+  if ((t >> 2) < nelemd) store4(out + (size_t)e * 16 + j * 4, r);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
 __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize, double rdt /* rhs_multiplier*dt */,
@@ -948,7 +973,9 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
                                                          const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
                                                          double* __restrict__ ps_v, double* __restrict__ Q,
                                                          int* __restrict__ bad, double* __restrict__ mn_out,
-                                                         double* __restrict__ mx_out, int force_generic, double* __restrict__ sink) {
+                                                         double* __restrict__ mx_out, int force_generic, double* __restrict__ sink,
+                                                         const double* __restrict__ dp2 /* null: the target grid of vertical_remap
+                                                         (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
   const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
@@ -978,7 +1005,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     // bracket search below replaces them
     double pin = 0.0;
     for (int k = 1; k <= NLEV; k++) {
-      double dpn = (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
+      double dpn = dp2 ? dp2[((size_t)e * NLEV + k - 1) * 16 + p] : (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
       pin = pin + dpn;
       S.z2[k - 1][p] = (k == NLEV) ? pio_prev : pin;  // pin(nlev+1) = pio(nlev+1)
     }

@@ -175,6 +175,29 @@ class HipMod:
     def vertical_remap(self, dt, np1_qdp):
         self._chk(self.L.tse_vertical_remap(self.h, dt, np1_qdp))
 
+    # ---- single calls of the public operators (derivative_mod / vertremap_mod), host arrays in and out ----
+    def divergence_sphere(self, v):
+        """v[ie][2][np][np] -> div[ie][np][np]  (derivative_mod.F90:2364)"""
+        v = np.ascontiguousarray(v, np.float64); assert v.shape == (self.nelemd, 2, NP, NP)
+        out = np.empty((self.nelemd, NP, NP))
+        self._chk(self.L.tse_divergence_sphere(self.h, _vp(v), _vp(out)))
+        return out
+
+    def laplace_sphere_wk(self, s):
+        """s[ie][np][np] -> laplace_sphere_wk(s)  (derivative_mod.F90:2418)"""
+        s = np.ascontiguousarray(s, np.float64); assert s.shape == (self.nelemd, NP, NP)
+        out = np.empty((self.nelemd, NP, NP))
+        self._chk(self.L.tse_laplace_sphere_wk(self.h, _vp(s), _vp(out)))
+        return out
+
+    def remap_q_ppm(self, qdp, dp1, dp2):
+        """remap_Q_ppm(Qdp,np,qsize,dp1,dp2) (prim_advection_mod.F90:98): qdp[ie][q][k][np][np], dp1/dp2[ie][k][np][np] -> new qdp"""
+        q = np.ascontiguousarray(qdp, np.float64).copy(); assert q.shape == (self.nelemd, self.qsize, NLEV, NP, NP)
+        d1 = np.ascontiguousarray(dp1, np.float64); d2 = np.ascontiguousarray(dp2, np.float64)
+        assert d1.shape == d2.shape == (self.nelemd, NLEV, NP, NP)
+        self._chk(self.L.tse_remap_q_ppm(self.h, _vp(q), _vp(d1), _vp(d2)))
+        return q
+
     def get_qminmax(self):
         qmin = np.empty((self.nelemd, self.qsize, NLEV)); qmax = np.empty_like(qmin)
         self._chk(self.L.tse_get_qminmax(self.h, _vp(qmin), _vp(qmax)))
