@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -23,7 +24,6 @@
 
 using namespace tse;
 
-static const int DSS_QB = 7;  // tracers per tracer-DSS block (3, 5, 7, 12 measured: 18.8, 18.4, 18.0, 18.0 ms for the final DSS)
 // TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
 static bool dss_on_read() { const char* e = getenv("TSE_DSS_ON_READ"); return !(e && e[0] == '0'); }
 
@@ -68,6 +68,13 @@ struct tse_ctx {
   std::vector<hipEvent_t> sync_events; size_t sync_next = 0;
   int *ord_bnd = nullptr, *ord_int = nullptr;
   int n_bnd = 0, n_int = 0;
+  // element patches of the scratch layout (tse_kernels.h): slot = patch*16 + position
+  int npatch = 0, nslots = 0, np_bnd = 0, np_int = 0;
+  int *slot_of = nullptr, *pslots = nullptr, *plist_bnd = nullptr, *plist_int = nullptr;
+  unsigned* pring = nullptr;
+  unsigned short* plds = nullptr;
+  int2* send_src_s = nullptr;   // the send columns in slot space
+  unsigned cse = 0;   // entries (points, halo columns) per chunk of a scratch plane
   bool halo() const { return ncol_send || ncol_recv; }
   // dcmip
   int dcmip_test = 0;
@@ -79,10 +86,16 @@ struct tse_ctx {
   struct Pending { const char* name; hipEvent_t a, b; };
   std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
   std::vector<hipEvent_t> free_events;
-  double *sink = nullptr;   // write-only dump of the remap's surplus tracer slots (18 x 72 doubles used)
+  double *sink = nullptr;   // write-only dump of the remap's surplus tracer slots: 16 columns x 72 levels, then two bounds areas
   double *eta2 = nullptr;   // with lvl_tmp: twin buffers of the level fields (k_dss_lvl writes out of place, then swap)
   bool t_zero_dirty = false;   // the per-stage stage-3 path used T as a plain [e][q][k][p] field (overwrites its zero elements)
-  size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: local elements, a zero element, the halo columns
+  size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: NCHUNK chunks of (slots, a zero slot, the halo columns)
+  Scr scr() const { return Scr{tps, cse}; }
+  unsigned zero0() const { return (unsigned)nslots * 16; }          // entry index of the zero slot within a chunk
+  unsigned halo0() const { return (unsigned)(nslots + 1) * 16; }    // entry index of halo column 0
+  GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_) const {
+    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_};
+  }
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
   DcmipTab* dcmip_tab = nullptr;   // level-only factors of the prescribed fields
@@ -302,17 +315,103 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     if (upload(&c->ord_bnd, ob) || upload(&c->ord_int, oi)) return 1;
   }
 
+  {
+    // Patches of the scratch layout: groups of <= 16 neighbouring elements (rows of up to 4 elements joined by their east links,
+    // up to 4 rows joined by the north link of each row's first element; no coordinates are needed and a patch may take any
+    // shape next to a cube seam or a rank boundary).  A DSS-on-read block owns one patch: what its slabs need from inside the
+    // patch travels through LDS, only the patch's halo ring comes from global memory.  Elements are taken in host order, so the
+    // patches of a full face tile it from its south-west corner.
+    std::vector<std::vector<int>> patches;
+    std::vector<int> pid(n, -1);
+    auto ring_size = [&](const std::vector<int>& cand, int me) {
+      std::vector<long> refs;
+      for (int e : cand)
+        for (int i = 0; i < 48; i++) {
+          const int2 t = tab[(size_t)e * 48 + i];
+          if (t.x == -1) continue;
+          if (t.x >= 0 && pid[t.x] == me) continue;                       // inside the candidate (marked below)
+          refs.push_back(t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1);
+        }
+      std::sort(refs.begin(), refs.end());
+      return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
+    };
+    for (int seed = 0; seed < n; seed++) {
+      if (pid[seed] >= 0) continue;
+      const int me = (int)patches.size();
+      for (int maxrows = 4; maxrows >= 1; maxrows--) {
+        std::vector<int> cand;
+        int rowstart = seed;
+        for (int r = 0; r < maxrows && rowstart >= 0 && pid[rowstart] < 0; r++) {
+          int e = rowstart, cnt = 0;
+          const int first = e;
+          while (e >= 0 && pid[e] < 0 && cnt < 4) { pid[e] = me; cand.push_back(e); cnt++; e = nbr[e * 8 + 1]; }   // east
+          rowstart = nbr[first * 8 + 3];                                                                         // north
+        }
+        if (ring_size(cand, me) <= NRMAX || maxrows == 1) { patches.push_back(cand); break; }
+        for (int e : cand) pid[e] = -1;   // too long a halo ring for one load per lane: fewer rows
+      }
+    }
+    c->npatch = (int)patches.size(); c->nslots = c->npatch * PS;
+    std::vector<int> slot_of(n, -1), pslots((size_t)c->nslots, -1);
+    for (int pi = 0; pi < c->npatch; pi++)
+      for (size_t i = 0; i < patches[pi].size(); i++) { slot_of[patches[pi][i]] = pi * PS + (int)i; pslots[(size_t)pi * PS + i] = patches[pi][i]; }
+    c->cse = (unsigned)(c->nslots + 1) * 16 + (unsigned)std::max(0, c->ncol_recv);
+    std::vector<unsigned> pring((size_t)c->npatch * NRMAX, c->zero0());
+    std::vector<unsigned short> plds((size_t)c->nslots * 48, (unsigned short)LDS_ZERO);
+    for (int pi = 0; pi < c->npatch; pi++) {
+      std::map<long, int> ring;   // source -> ring entry
+      for (size_t i = 0; i < patches[pi].size(); i++) {
+        const int e = patches[pi][i];
+        for (int k = 0; k < 48; k++) {
+          const int2 t = tab[(size_t)e * 48 + k];
+          unsigned short ent = (unsigned short)LDS_ZERO;
+          if (t.x >= 0 && pid[t.x] == pi) ent = (unsigned short)((slot_of[t.x] - pi * PS) * 16 + t.y);
+          else if (t.x != -1) {
+            const long key = t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1;
+            auto it = ring.find(key);
+            if (it == ring.end()) {
+              if ((int)ring.size() >= NRMAX) return fail("tse_init: halo ring of patch %d exceeds %d entries", pi, NRMAX);
+              it = ring.emplace(key, (int)ring.size()).first;
+              pring[(size_t)pi * NRMAX + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + t.y : c->halo0() + (unsigned)(-(t.x + 2));
+            }
+            ent = (unsigned short)(PS * 16 + it->second);
+          }
+          plds[((size_t)pi * PS + i) * 48 + k] = ent;
+        }
+      }
+    }
+    std::vector<int2> send_s(send_src);
+    for (int2& t : send_s) t.x = slot_of[t.x];
+    // rank-boundary patches first, as the elements above
+    std::vector<int> pb, pin;
+    {
+      std::vector<int> ob;   // (host copy of ord_bnd)
+      std::vector<char> isb(n, 0);
+      for (const int2& q : send_src) isb[q.x] = 1;
+      for (const int2& q : mm_src) isb[q.x] = 1;
+      for (int pi = 0; pi < c->npatch; pi++) {
+        bool b = false;
+        for (int e : patches[pi]) b = b || isb[e];
+        (b ? pb : pin).push_back(pi);
+      }
+    }
+    c->np_bnd = (int)pb.size(); c->np_int = (int)pin.size();
+    if (upload(&c->slot_of, slot_of) || upload(&c->pslots, pslots) || upload(&c->pring, pring) || upload(&c->plds, plds) ||
+        upload(&c->send_src_s, send_s) || upload(&c->plist_bnd, pb) || upload(&c->plist_int, pin)) return 1;
+  }
+
   // ---- state -------------------------------------------------------------------------------------
   const size_t lev = c->lev(), trc = c->trc();
-  // scratch fields T, B: one plane per tracer = local elements + one all-zero element (target of empty gather slots) +
-  // the received halo columns (DSS-on-read reads them from there); see tse_kernels.h
-  c->tps = (((size_t)(n + 1) * 16 * TLEV + (size_t)std::max(0, c->ncol_recv) * NLEV) + 15) / 16 * 16;
+  // scratch fields T, B: one plane per tracer = NCHUNK chunks of (element slots + one all-zero slot, the target of empty DSS
+  // contributions, + the received halo columns, which DSS-on-read reads from there); see tse_kernels.h
+  c->tps = ((size_t)NCHUNK * c->cse * CL + 15) / 16 * 16;
+  if (c->tps < (size_t)n * 16 * NLEV) return fail("tse_init: scratch plane smaller than a tracer plane");
   if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps))
     return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
   HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
-      dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 32) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
+      dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)NLEV * c->qsize) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
   const size_t mm = (size_t)n * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
   HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
@@ -366,7 +465,8 @@ void tse_finalize(tse_ctx* c) {
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
-                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int};
+                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->pslots, c->plist_bnd,
+                  c->plist_int, c->pring, c->plds, c->send_src_s};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   resolve_timers(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
@@ -484,10 +584,19 @@ int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size
   return 0;
 }
 int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
-  size_t mm = (size_t)c->nelemd * c->qsize * NLEV;
+  const size_t mm = (size_t)c->nelemd * c->qsize * NLEV;
   HIPCHK(hipStreamSynchronize(c->stream));
-  if (qmin) HIPCHK(hipMemcpy(qmin, c->qmin, mm * 8, hipMemcpyDeviceToHost));
-  if (qmax) HIPCHK(hipMemcpy(qmax, c->qmax, mm * 8, hipMemcpyDeviceToHost));
+  std::vector<double> h(mm);
+  double* outs[2] = {qmin, qmax};
+  const double* devs[2] = {c->qmin, c->qmax};
+  for (int a = 0; a < 2; a++) {
+    if (!outs[a]) continue;
+    HIPCHK(hipMemcpy(h.data(), devs[a], mm * 8, hipMemcpyDeviceToHost));
+    for (int e = 0; e < c->nelemd; e++)          // device layout [e][k / CL][q][k % CL] (tse_kernels.h: mm_idx) -> [e][q][k]
+      for (int q = 0; q < c->qsize; q++)
+        for (int k = 0; k < NLEV; k++)
+          outs[a][((size_t)e * c->qsize + q) * NLEV + k] = h[(((size_t)e * NCHUNK + k / CL) * c->qsize + q) * CL + (k % CL)];
+  }
   return 0;
 }
 
@@ -538,8 +647,8 @@ static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int n
   const int nq = c->qsize * NLEV;
   if (!c->ncol_send) return 0;
   size_t tot = (size_t)c->ncol_send * nq;
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_send, nq, c->send_src, scratch,
-                     (const double*)nullptr, c->sendbuf, nlyr_halo, 0, c->tps, 0);
+  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_send, nq, c->send_src_s, scratch,
+                     (const double*)nullptr, c->sendbuf, nlyr_halo, 0, c->scr(), 0);
   LAUNCH_CHECK();
   return 0;
 }
@@ -549,7 +658,7 @@ static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_level
   if (!c->ncol_send || !var) return 0;
   size_t tv = (size_t)c->ncol_send * NLEV;
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var,
-                     c->spheremp, c->sendbuf, nq + NLEV, nq, (size_t)0, var_levels);
+                     c->spheremp, c->sendbuf, nq + NLEV, nq, Scr{0, 0}, var_levels);
   LAUNCH_CHECK();
   return 0;
 }
@@ -567,8 +676,8 @@ static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo)
   if (!c->ncol_recv) return 0;
   const int nq = c->qsize * NLEV;
   size_t tot = (size_t)c->ncol_recv * nq;
-  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->tps,
-                     c->nelemd);
+  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->scr(),
+                     c->halo0());
   LAUNCH_CHECK();
   return 0;
 }
@@ -579,7 +688,7 @@ static int nbr_minmax_kernel(tse_ctx* c) {
   {
     Scope s(c, "minmax");
     hipLaunchKernelGGL(k_nbr_minmax, dim3(8 * ((c->nelemd + 7) / 8)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->nbr, c->qmin,
-                       c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m);
+                       c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m, c->order);
     LAUNCH_CHECK();
   }
   std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
@@ -606,18 +715,17 @@ static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
   std::swap(*varp, *twin);
   return 0;
 }
-// tracer DSS pass src (scratch layout) -> dst (standard layout), optionally fused with qdp_time_avg and the next step's bounds
-static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, int nlyr_halo) {
+// tracer DSS pass src (scratch layout, halo columns filled) -> dst (standard layout), optionally fused with qdp_time_avg and the
+// next step's bounds
+static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg) {
   Scope s(c, "dss");
-  const int qb = DSS_QB, nqc = (c->qsize + qb - 1) / qb;
-  const dim3 grid2(8 * dss2_blocks_per_xcd(c->nelemd) * nqc);
-  // the remote (halo) source is only 8-byte aligned per level pair when nlyr_halo is even: qsize*72 (+ 72) always is
+  const GatherArgs ga = c->gargs(nullptr, c->nelemd, nullptr, c->npatch);
+  const dim3 grid(patch_blocks(c->npatch)), blk(FLAT_THREADS);
   if (Qn0_avg)
-    hipLaunchKernelGGL(k_dss_t2<1>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                       Qn0_avg, c->recvbuf, nlyr_halo, c->order, (const double*)c->dp, c->qmin2, c->qmax2, c->tps);
+    hipLaunchKernelGGL(k_dss_patch<1>, grid, blk, 0, c->stream, c->qsize, src, dst, Qn0_avg, (const double*)c->dp, c->qmin2, c->qmax2, ga);
   else
-    hipLaunchKernelGGL(k_dss_t2<0>, grid2, dim3(DSS2_THREADS), 0, c->stream, c->nelemd, c->qsize, qb, c->dss_tab, c->rspheremp, src, dst,
-                       (const double*)nullptr, c->recvbuf, nlyr_halo, c->order, (const double*)nullptr, (double*)nullptr, (double*)nullptr, c->tps);
+    hipLaunchKernelGGL(k_dss_patch<0>, grid, blk, 0, c->stream, c->qsize, src, dst, (const double*)nullptr, (const double*)nullptr,
+                       (double*)nullptr, (double*)nullptr, ga);
   LAUNCH_CHECK();
   return 0;
 }
@@ -633,7 +741,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
   const int nq = c->qsize * NLEV;
   const dim3 grid(flat_blocks(c->nelemd)), blk(FLAT_THREADS);
-  const GatherArgs plain{nullptr, nullptr, c->tps, nullptr, c->nelemd};
+  const GatherArgs plain = c->gargs(nullptr, c->nelemd, nullptr, 0);
   if (rhs == 0) {
     if (fused_mm && c->mm_valid == n0_qdp) {
       // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
@@ -666,20 +774,22 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     // (lap, Qmin, Qmax) = 3*qsize*nlev layers (viscosity_mod.F90:389-391); here the Laplacian and the bounds travel separately.
     if (pack_tracers(c, c->stream, c->B, nq)) return 1;
     if (halo_exchange(c, nq, 0, c->stream)) return 1;
-    if (dss_tracer_pass(c, c->B, c->T, nullptr, nq)) return 1;
+    if (unpack_halo(c, c->stream, c->B, nq)) return 1;
+    if (dss_tracer_pass(c, c->B, c->T, nullptr)) return 1;
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance2");
     hipLaunchKernelGGL(k_advance<2>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, c->T, c->B, c->vn0, c->dp, c->divdp,
                        c->divdp_proj, c->qmin, c->qmax, c->dp0, plain);
     LAUNCH_CHECK();
   }
-  const double* pre = rhs == 2 ? c->B : c->T;
+  double* pre = rhs == 2 ? c->B : c->T;
   const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
   // edgeVpack(Qdp) + edgeVpack(spheremp*DSSvar) -> bndry_exchangeV -> edgeVunpack + rspheremp  (:911-960)
   if (pack_tracers(c, c->stream, pre, nq + NLEV)) return 1;
   if (var && pack_var(c, c->stream, *var, var_levels)) return 1;
   if (halo_exchange(c, nq + NLEV, 0, c->stream)) return 1;
-  if (dss_tracer_pass(c, pre, Qnp1, avg, nq + NLEV)) return 1;
+  if (unpack_halo(c, c->stream, pre, nq + NLEV)) return 1;
+  if (dss_tracer_pass(c, pre, Qnp1, avg)) return 1;
   return dss_level_var(c, var, var_levels);
 }
 
@@ -714,16 +824,24 @@ static hipEvent_t next_sync_event(tse_ctx* c) {
   return e;
 }
 
+// the part of the local mesh one launch covers: everything (single rank), the elements / patches that touch another rank, the rest
+struct Work { const int* order; int nwork; const int* plist; int npwork; };
+static Work work_of(const tse_ctx* c, int part) {
+  if (part == 0) return Work{nullptr, c->nelemd, nullptr, c->npatch};
+  if (part == 1) return Work{c->ord_bnd, c->n_bnd, c->plist_bnd, c->np_bnd};
+  return Work{c->ord_int, c->n_int, c->plist_int, c->np_int};
+}
+
 template <class Launch, class CommWork>
-static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (order, nwork) */, CommWork comm_work /* () on c->comm_stream */) {
+static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (Work) */, CommWork comm_work /* () on c->comm_stream */) {
   Scope s(c, timer);
-  if (!c->halo()) return launch((const int*)nullptr, c->nelemd);
-  if (launch((const int*)c->ord_bnd, c->n_bnd)) return 1;
+  if (!c->halo()) return launch(work_of(c, 0));
+  if (launch(work_of(c, 1))) return 1;
   hipEvent_t evB = next_sync_event(c), evC = next_sync_event(c);
   HIPCHK(hipEventRecord(evB, c->stream));
   HIPCHK(hipStreamWaitEvent(c->comm_stream, evB, 0));
   if (c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
-  if (c->n_int && launch((const int*)c->ord_int, c->n_int)) return 1;
+  if (launch(work_of(c, 2))) return 1;
   if (!c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
   HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
   return 0;
@@ -735,8 +853,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   const int nq = c->qsize * NLEV;
   const dim3 blk(FLAT_THREADS);
   hipStream_t cs = c->comm_stream;
-  auto plain = [&](const int* ord, int nw) { return GatherArgs{nullptr, nullptr, c->tps, ord, nw}; };
-  auto gath = [&](const int* ord, int nw) { return GatherArgs{c->dss_tab, c->rspheremp, c->tps, ord, nw}; };
+  auto gargs = [&](const Work& w) { return c->gargs(w.order, w.nwork, w.plist, w.npwork); };
 
   // ---- stage 1 (rhs_multiplier 0, DSS extra = divdp_proj): bounds, neighbour min/max, advance Qdp(n0) -> T
   if (c->mm_valid == n0_qdp) {
@@ -765,9 +882,10 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     if (nbr_minmax_kernel(c)) return 1;
   }
   if (split_stage(c, "advance0",
-        [&](const int* ord, int nw) -> int {
-          hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qn0,
-                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, plain(ord, nw));
+        [&](Work w) -> int {
+          if (!w.nwork) return 0;
+          hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(w.nwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qn0,
+                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->T, nq + NLEV) || pack_var(c, cs, c->divdp_proj, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
                               unpack_halo(c, cs, c->T, nq + NLEV); })) return 1;
@@ -775,9 +893,10 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
 
   // ---- stage 2 (rhs_multiplier 1, DSS extra = eta_dot_dpdn): T (+) edges -> B
   if (split_stage(c, "advance1",
-        [&](const int* ord, int nw) -> int {
-          hipLaunchKernelGGL((k_advance<1, 1>), dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->T,
-                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gath(ord, nw));
+        [&](Work w) -> int {
+          if (!w.npwork) return 0;
+          hipLaunchKernelGGL((k_advance<1, 1>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->T,
+                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->eta, NLEVP) || halo_exchange(c, nq + NLEV, 0, cs) ||
                               unpack_halo(c, cs, c->B, nq + NLEV); })) return 1;
@@ -787,22 +906,25 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   // 3a: B (+) edges -> Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, element min/max; the bounds and the
   //     Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
   if (split_stage(c, "lap",
-        [&](const int* ord, int nw) -> int {
-          hipLaunchKernelGGL(k_lap1<1>, dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
-                             c->divdp_proj, c->qmin, c->qmax, Qnp1, gath(ord, nw));
+        [&](Work w) -> int {
+          if (!w.npwork) return 0;
+          hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
+                             c->divdp_proj, c->qmin, c->qmax, Qnp1, gargs(w));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
                               unpack_halo(c, cs, c->T, nq); })) return 1;
   if (nbr_minmax_kernel(c)) return 1;
   // 3b: Qdp(np1), T (+) edges -> B (2nd Laplacian + biharmonic scaling + advance + limiter)
   if (split_stage(c, "advance2",
-        [&](const int* ord, int nw) -> int {
-          hipLaunchKernelGGL((k_advance<2, 2>), dim3(flat_blocks(nw)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qnp1,
-                             (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gath(ord, nw));
+        [&](Work w) -> int {
+          if (!w.npwork) return 0;
+          hipLaunchKernelGGL((k_advance<2, 2>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qnp1,
+                             (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs); })) return 1;
+        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
+                              unpack_halo(c, cs, c->B, nq + NLEV); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
-  if (dss_tracer_pass(c, c->B, Qnp1, Qn0, nq + NLEV)) return 1;
+  if (dss_tracer_pass(c, c->B, Qnp1, Qn0)) return 1;
   return dss_level_var(c, &c->omega_p, NLEV);
 }
 
@@ -819,8 +941,10 @@ int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) 
     gor = false;
   }
   if (gor) {
-    if (c->t_zero_dirty) {   // restore the all-zero element of every plane of T
-      HIPCHK(hipMemset2DAsync(c->T + (size_t)c->nelemd * 16 * TLEV, c->tps * 8, 0, (size_t)16 * TLEV * 8, c->qsize, c->stream));
+    if (c->t_zero_dirty) {   // restore the all-zero slots of T
+      const int tot = c->qsize * NCHUNK * 16 * CL;
+      hipLaunchKernelGGL(k_zero_slot, dim3((tot + 255) / 256), dim3(256), 0, c->stream, c->qsize, c->T, c->scr(), c->zero0());
+      LAUNCH_CHECK();
       c->t_zero_dirty = false;
     }
     if (advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp)) return 1;

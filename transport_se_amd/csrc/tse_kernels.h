@@ -2,43 +2,50 @@
 //
 // HBM layout (all fp64, point index p = j*4+i fastest):
 //   tracer fields  Qdp[tl][e][q][k][p]
-//   pre-DSS scratch T, B: tracer-major planes, level fastest: T[q][slot], slot = (e*16+p)*NLEV + k for the local elements,
-//                  then one all-zero element (e = nelemd), then the received halo columns [col][k]; plane stride `tps`
-//                  doubles (tse_api.hip).  A plane is < 4 GB, so the DSS-on-read kernels address it with one uniform
-//                  base + 32-bit byte offsets.
+//   pre-DSS scratch T, B: tracer-major planes; inside a plane the 72 levels are cut into NCHUNK chunks of CL = 4 levels and
+//                  a chunk holds, level fastest, T[q][kc][slot][p][kk]: the element slots (elements regrouped into
+//                  patches of <= 16 neighbouring elements, tse_api.hip), then one all-zero slot (target of empty DSS
+//                  contributions), then the received halo columns [col][kk].  Plane stride `tps` doubles, `cse` entries
+//                  (points / halo columns) per chunk.  A plane is < 4 GB, so the DSS-on-read kernels address it with one
+//                  uniform base + 32-bit byte offsets.
 //   level fields   dp, divdp, divdp_proj, omega_p, dp3d [e][k][p]; vn0[e][k][c][p]; eta_dot_dpdn[e][73][p]
-//   bounds         qmin/qmax[e][q][k]
+//   bounds         qmin/qmax[e][kc][q][kk] (mm_idx): the 4 levels of a chunk fastest, then the tracer, so that the 32 bytes a
+//                  (patch x chunk) block needs per element and tracer share their line with the next three tracers
 //   metric         Dinv[e][p][4], metdet/rmetdet/spheremp/rspheremp[e][p]
-// Every slab kernel uses the row-per-lane layout of tse_device.h: thread = (slab (e,k) of the flattened index, row j),
-// looping over the tracers so that everything that depends on (e,k) only -- Vstar, dp, dp_star, the metric rows --
-// is computed once and stays in registers for all qsize tracers.
+// Every slab kernel uses the row-per-lane layout of tse_device.h: thread = (slab (e,k), row j), looping over the tracers so
+// that everything that depends on (e,k) only -- Vstar, dp, dp_star, the metric rows -- is computed once and stays in
+// registers for all qsize tracers.
 #pragma once
 #include <type_traits>
 #include "tse_device.h"
 
 namespace tse {
 
-// The slab kernels (k_divdp, k_qminmax, k_advance, k_lap1) run over the flattened slab index s = e*NLEV + k instead: a
+// The plain slab kernels (k_divdp, k_qminmax, k_advance<*,0>, k_lap1<0>) run over the flattened slab index s = e*NLEV + k: a
 // 72-level element is 4.5 waves, so element-sized blocks idle 10% of their lanes and -- worse -- come in units of 5 waves,
 // which leaves SIMD wave slots empty whenever the register budget allows 2 or 3 waves per SIMD (8 or 12 per CU).
 constexpr int FLAT_THREADS = 256;
-// Row pitch (levels) of the scratch layout.  Measured: padding the rows to 80 levels (every [p] row on a 128-B line) is 3 %
-// slower than the dense 72, and a wave mapping that starts every 16-level chunk on a multiple of 16 changes nothing.
-#ifndef TSE_TLEV
-#define TSE_TLEV NLEV
-#endif
-constexpr int TLEV = TSE_TLEV;
+// Scratch layout: CL levels per chunk.  The DSS-on-read kernels work on blocks of (patch of 16 element slots) x (one chunk):
+// 16 slots x 4 levels x 4 rows = 256 lanes, and a slot's 16 points x 4 levels are 512 contiguous bytes.
+constexpr int CL = 4;
+constexpr int NCHUNK = NLEV / CL;
+static_assert(NLEV % CL == 0 && CL % 2 == 0, "chunks hold whole level pairs");
+constexpr int PS = 16;        // element slots per patch
+constexpr int NRMAX = 128;    // halo-ring entries of a patch (a full 4x4 patch has 92; tse_api.hip splits patches that need more)
+struct Scr { size_t tps; unsigned cse; };   // plane stride (doubles), entries per chunk
+// element index of T[q][k / CL][slot][p][k % CL]
+__device__ __forceinline__ size_t t_idx(Scr S, int q, int slot, int p, int k) {
+  return (size_t)q * S.tps + ((size_t)(k / CL) * S.cse + (size_t)slot * 16 + p) * CL + (k % CL);
+}
+// qmin/qmax(k,q,e) of prim_advection_mod (:459) in the device layout [e][k / CL][q][k % CL]
+__device__ __forceinline__ size_t mm_idx(int e, int q, int k, int qsize) { return (((size_t)e * NCHUNK + k / CL) * qsize + q) * CL + (k % CL); }
 // Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
-// XCD a contiguous range of slabs: the two blocks that share an element then write their halves of the T[q][e][p][:]
-// rows through the same L2 (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
+// XCD a contiguous range of slabs (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
 struct SlabId { int e, k; bool live; };
-// `order` (optional): the strip walk of tse_api.hip -- consecutive slots are elements that are neighbours in both directions,
-// so that the ~60 elements an XCD works on at a time form a compact patch and the DSS-on-read gathers of one element hit
-// lines its neighbours are reading at the same moment (L2) instead of going to HBM for the north/south edges.
-__device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ order = nullptr) {
+__device__ __forceinline__ SlabId flat_slab(int nwork, const int* __restrict__ order = nullptr) {
   const int per = gridDim.x >> 3, lb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
   SlabId s;
-  const int n = nelemd * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
+  const int n = nwork * NLEV, gs = lb * (FLAT_THREADS / 4) + (threadIdx.x >> 2);
   s.live = gs < n;
   const int g = s.live ? gs : n - 2 + (gs & 1);   // idle tail lanes recompute one of the last two slabs (their level parity
                                                   // is kept: lanes l and l+4 stay a level pair) and store nothing
@@ -47,10 +54,7 @@ __device__ __forceinline__ SlabId flat_slab(int nelemd, const int* __restrict__ 
   s.e = order ? order[slot] : slot;
   return s;
 }
-inline int flat_blocks(int nelemd) { return 8 * ((nelemd * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
-
-// element index of T[q][e][p][k] in the tracer-major scratch layout
-__device__ __forceinline__ size_t t_idx(size_t tps, int q, int e, int p, int k) { return (size_t)q * tps + ((size_t)e * 16 + p) * TLEV + k; }
+inline int flat_blocks(int nwork) { return 8 * ((nwork * NLEV * 4 + 8 * FLAT_THREADS - 1) / (8 * FLAT_THREADS)); }
 
 struct GeoPtrs {
   const double* Dinv; const double* metdet; const double* rmetdet; const double* spheremp; const double* rspheremp;
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
     double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     if (j == 0 && k < NLEV) {
-      qmin[((size_t)e * qsize + q) * NLEV + k] = mn;
-      qmax[((size_t)e * qsize + q) * NLEV + k] = mx;
+      qmin[mm_idx(e, q, k, qsize)] = mn;
+      qmax[mm_idx(e, q, k, qsize)] = mx;
     }
   }
 }
@@ -134,12 +138,18 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
 __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
                                                     const double* __restrict__ in_min, const double* __restrict__ in_max,
                                                     double* __restrict__ out_min, double* __restrict__ out_max,
-                                                    const double* __restrict__ recvbuf, int nlyr_halo) {
-  // block = element; the 8 XCDs each walk a contiguous range of elements so that an element's bounds are re-read by
-  // its neighbours out of the same L2 (every value is needed by up to 9 elements)
+                                                    const double* __restrict__ recvbuf, int nlyr_halo, const int* __restrict__ order) {
+  // block = element; the 8 XCDs each walk a contiguous range of elements in the strip order of tse_api.hip (the same the
+  // DSS kernels use), so that an element's bounds are re-read by its neighbours -- west/east one block, south/north
+  // about eight blocks later -- out of the same L2 (every value is needed by up to 9 elements; 40 KB per element)
   const int S8 = (nelemd + 7) >> 3;
-  const int e = (blockIdx.x & 7) * S8 + (blockIdx.x >> 3);
-  if (e >= nelemd) return;
+  const int slot = (blockIdx.x & 7) * S8 + (blockIdx.x >> 3);
+  if (slot >= nelemd) return;
+#ifdef TSE_MM_PLAIN_ORDER
+  const int e = slot;
+#else
+  const int e = order[slot];
+#endif
   const int m = qsize * NLEV;
   const double *pmn[8], *pmx[8];
 #pragma unroll
@@ -165,117 +175,167 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
 
 // ---------------------------------------------------------------------------------------------------
 // DSS on read.  In the whole-step path the DSS'd field between two RK stages is never written to memory: the consuming
-// slab kernel assembles rspheremp*DSS(T) for its own row from the producer's pre-DSS scratch T[q][e][p][k] -- the lane's 4
-// own points plus up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges,
-// then the corner) and the same inverse-mass multiply as k_dss_t2, so the value is bit-identical to what the DSS pass would
-// have stored.  That removes one read+write pass over the tracers per fused hand-over.
-// order/nwork: the element slots this launch walks -- order[0..nwork) (nullptr: elements 0..nwork).  A multi-rank step
-// launches every slab kernel twice: first over the elements that touch another rank, so that their halo can travel while
-// the second launch computes the interior elements (tse_api.hip).
-struct GatherArgs { const int2* tab; const double* rspheremp; size_t tps; const int* order; int nwork; };
-// Addresses are 32-bit byte offsets into the tracer's plane of the scratch layout (uniform base + VGPR offset loads, no
-// per-load address arithmetic).  An empty table slot points into the all-zero element behind the local ones, a remote slot
-// into the halo columns that k_unpack_halo copied behind that, so all loads are unconditional and alike.
+// slab kernel assembles rspheremp*DSS(T) for its own row from the producer's pre-DSS scratch -- the lane's 4 own points plus
+// up to 8 neighbour edge/corner values -- with the same table, the same summation order (S, E, N, W edges, then the
+// corner) and the same inverse-mass multiply as k_dss_patch, so the value is bit-identical to what the DSS pass would have
+// stored.  That removes one read+write pass over the tracers per fused hand-over.
 //
-// Who fetches what.  A slab needs its 16 own values and 20 neighbour values -- 8 for each of the rows j = 0 and 3 (points
-// i = 0 and 3 take up to two edges and a corner, i = 1,2 one edge), 2 for each of the rows j = 1,2 (west and east edge).
-//  * The quad shares the neighbour values: every lane is responsible for 5 of the 20 (the middle rows take, besides their own
-//    two, the third contribution of point 0 and the contributions of points 1 and 2 of the edge row next to them) and hands
-//    them over with one quad_perm DPP move each.
-//  * The two lanes that hold the levels (2m, 2m+1) of the same row (lanes l and l+4) share every fetch: the scratch layout
-//    is level-fastest, so one 16-byte load returns both levels.  The even lane loads own points 0,1 and fetches 0,2,4; the
-//    odd lane own points 2,3 and fetches 1,3; the halves are swapped with ds_swizzle (lane ^ 4).
-// That is 5 sixteen-byte loads per lane and tracer (every byte fetched once) instead of 12 eight-byte loads: measured,
-// eight-byte gather loads cost about 1 ms per load instruction and kernel launch even when they hit in L2.
-struct GatherRaw { double2 w[2], g[3]; };
-struct RowGather {
-  unsigned own;      // T[.][e][j*4 + (odd ? 2 : 0)][k & ~1]; the second own load is one row (TLEV*8 bytes) further
-  unsigned go[3];    // the lane's three fetches (level pair)
-  double rs[4];
+// Where the neighbour values come from.  Each of them is some other element's own value, so a block that owns a PATCH of
+// neighbouring elements already loads most of what its slabs need: block = (patch of <= 16 element slots, one chunk of 4
+// levels).  Per tracer every lane loads its own points (two 16-byte loads shared with the lane that holds the other level
+// of the pair), the block loads the patch's HALO RING -- the edge/corner columns of elements outside the patch, 92 of them
+// for a full 4x4 patch against 320 neighbour values inside -- with one more 16-byte load per lane, everything is published
+// to LDS, and after one workgroup barrier the 20 neighbour values of a slab are LDS reads.  Compared with gathering them
+// from global memory this fetches 0.36 instead of 1.25 times the field on top of the own values: the gathers of
+// concurrently running blocks did not meet in the XCD's L2 (blocks drift apart by several tracers), so they were HBM traffic.
+// LDS is double-buffered over the tracers; one barrier per tracer separates the publish from the reads, and the buffer
+// written for tracer q+2 was last read before the barrier of tracer q+1.
+//
+// Who reads what (as before): the quad shares the neighbour values -- every lane is responsible for 5 of the slab's 20 (the
+// middle rows take, besides their own two, the third contribution of point 0 and the contributions of points 1 and 2 of
+// the edge row next to them) and hands them over with one quad_perm DPP move each.
+//
+// plist/npwork: the patches this launch walks (nullptr: patches 0..npwork).  A multi-rank step launches every slab kernel
+// twice: first over the patches (plain kernels: elements, order/nwork) that touch another rank, so that their halo can travel
+// while the second launch computes the interior (tse_api.hip).
+struct GatherArgs {
+  Scr S;
+  const int* slot_of;              // element -> slot of the scratch layout
+  const int* order; int nwork;     // plain slab kernels: element list of this launch
+  const double* rspheremp;
+  const int* pslots;               // [npatch][PS] element of a slot, -1 = hole
+  const unsigned* pring;           // [npatch][NRMAX] ring entry -> entry index within a chunk (slot*16+p, zero slot, halo column)
+  const unsigned short* plds;      // [npatch][PS][16][3] DSS contribution -> LDS entry (own-patch point, ring entry, zero entry)
+  const int* plist; int npwork;    // patch list of this launch
 };
+constexpr int LDS_ZERO = PS * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
+struct PatchLds { double v[2][LDS_ENT][CL]; };   // 2 x 12.3 KB
+
 __device__ __forceinline__ double swz_xor4(double x) {   // value of lane ^ 4 (the other level of the pair)
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_ds_swizzle(lo, 0x101F); hi = __builtin_amdgcn_ds_swizzle(hi, 0x101F);   // and 0x1f, or 0, xor 4
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ void gather_setup(RowGather& R, const GatherArgs& A, int nelemd, int e, int j, int k) {
-  const bool edge = (j == 0) | (j == 3), odd = k & 1;
-  const int kb = k & ~1;
+
+// block -> (patch, chunk), lane -> (slot of the patch, level of the chunk, row).  The 8 XCDs each take a contiguous range of
+// patches and walk it chunk by chunk, so that the patches whose own values are a block's ring are in flight on the same XCD.
+struct PatchId { int patch, slot, e, k, j; bool live, any; };
+inline int patch_blocks(int npwork) { return 8 * ((npwork + 7) / 8) * NCHUNK; }
+__device__ __forceinline__ PatchId patch_slab(const GatherArgs& A) {
+  const int npx = (A.npwork + 7) >> 3, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int kc = i / npx, pi = x * npx + (i - kc * npx);
+  PatchId P;
+  P.any = pi < A.npwork;
+  P.patch = P.any ? (A.plist ? A.plist[pi] : pi) : 0;
+  const int sl = threadIdx.x >> 4;
+  P.k = kc * CL + ((threadIdx.x >> 2) & (CL - 1));
+  P.j = threadIdx.x & 3;
+  P.slot = P.patch * PS + sl;
+  const int e = A.pslots[P.slot];
+  P.live = e >= 0;
+  P.e = P.live ? e : A.pslots[P.patch * PS];   // a hole recomputes the patch's first element and stores nothing
+  return P;
+}
+
+struct GatherRaw { double2 w[2], r; };   // the lane's two own loads and its ring load
+struct RowGather {
+  unsigned own;        // plane-relative byte offset of T[.][kc][slot][j*4 + (odd ? 2 : 0)][kk & ~1]; the second own load is CL*8 further
+  unsigned ring;       // plane-relative byte offset of the lane's half of a ring entry
+  unsigned lw, lwr;    // LDS byte offsets (buffer 0) where the lane publishes its first own load / its ring load
+  unsigned lr[5];      // LDS byte offsets (buffer 0) of the lane's five neighbour values
+  double rs[4];
+};
+__device__ __forceinline__ void gather_setup(RowGather& R, PatchLds& L, const GatherArgs& A, const PatchId& P) {
+  if (threadIdx.x < 2 * CL) L.v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;   // target of absent contributions (read after the first barrier)
+  const int j = P.j, kk = P.k & (CL - 1), kc = P.k / CL, sl = P.slot - P.patch * PS;
+  const bool edge = (j == 0) | (j == 3), odd = kk & 1;
   const int jt = j == 1 ? 0 : (j == 2 ? 3 : j);   // the edge row a middle row helps
-  // (row, point, contribution index) of the row's five fetches; this lane loads f = {0,2,4} (even level) or {1,3,3} (odd)
+  // (row, point, contribution index) of the row's five fetches
   const int rw[5] = {j, j, edge ? j : jt, edge ? j : jt, edge ? j : jt};
   const int pt[5] = {0, edge ? 0 : 3, edge ? 3 : 0, edge ? 3 : 1, edge ? 3 : 2};
   const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
-  R.own = (unsigned)(((e * 16 + j * 4 + (odd ? 2 : 0)) * TLEV + kb) * 8);
-  int2 tt[3];
+  const unsigned chunk0 = (unsigned)kc * A.S.cse;                       // first entry of the chunk
+  const int p0 = j * 4 + (odd ? 2 : 0);
+  R.own = ((chunk0 + (unsigned)P.slot * 16 + p0) * CL + (kk & ~1)) * 8u;
+  R.lw = (unsigned)((sl * 16 + p0) * CL + (kk & ~1)) * 8u;
+  unsigned short le[5];
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
-    const int se = 2 * m, so = m < 2 ? 2 * m + 1 : 3;
-    const int r = odd ? rw[so] : rw[se], p = odd ? pt[so] : pt[se], c = odd ? cn[so] : cn[se];
-    tt[m] = A.tab[((size_t)e * 16 + r * 4 + p) * 3 + c];
-  }
+  for (int m = 0; m < 5; m++) le[m] = A.plds[((size_t)P.slot * 16 + rw[m] * 4 + pt[m]) * 3 + cn[m]];
+  // ring: lanes 2r, 2r+1 load the two level pairs of ring entry r; lanes beyond the patch's ring re-read the zero slot
+  const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
+  const unsigned ent = A.pring[(size_t)P.patch * NRMAX + r];           // unused entries of the table hold the zero slot
+  R.ring = ((chunk0 + ent) * CL + half * 2) * 8u;
+  R.lwr = (unsigned)((PS * 16 + r) * CL + half * 2) * 8u;              // r < NRMAX = 128 = 256 lanes / 2
 #pragma unroll
-  for (int m = 0; m < 3; m++) {
-    const int2 t = tt[m];
-    unsigned slot = (unsigned)(nelemd * 16 * TLEV + kb);                                   // the zero element
-    if (t.x >= 0) slot = (unsigned)((t.x * 16 + t.y) * TLEV + kb);
-    else if (t.x <= -2) slot = (unsigned)((nelemd + 1) * 16 * TLEV + (-(t.x + 2)) * NLEV + kb);   // halo column -(t.x+2)
-    R.go[m] = slot * 8u;
-  }
-  load4(A.rspheremp + (size_t)e * 16 + j * 4, R.rs);
+  for (int m = 0; m < 5; m++) R.lr[m] = ((unsigned)le[m] * CL + kk) * 8u;
+  load4(A.rspheremp + (size_t)P.e * 16 + j * 4, R.rs);
 }
-// loads only, all 5 in flight together; every use comes later.
+// loads only, all 3 in flight together; every use comes later.
 // The empty asm keeps the offsets opaque inside the tracer loop: otherwise their zero-extension is hoisted out of the loop
 // (two registers per offset) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
 __device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q, GatherRaw& raw) {
-  asm volatile("" : "+v"(R.own), "+v"(R.go[0]), "+v"(R.go[1]), "+v"(R.go[2]));
-  const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.tps);   // wave-uniform
+  asm volatile("" : "+v"(R.own), "+v"(R.ring));
+  const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.S.tps);   // wave-uniform
   raw.w[0] = *reinterpret_cast<const double2*>(pq + R.own);
-  raw.w[1] = *reinterpret_cast<const double2*>(pq + (R.own + (unsigned)(TLEV * 8)));
-#pragma unroll
-  for (int m = 0; m < 3; m++) raw.g[m] = *reinterpret_cast<const double2*>(pq + R.go[m]);
+  raw.w[1] = *reinterpret_cast<const double2*>(pq + (R.own + (unsigned)(CL * 8)));
+  raw.r = *reinterpret_cast<const double2*>(pq + R.ring);
 }
-// the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
-__device__ __forceinline__ void gather_sum(const RowGather& R, int j, int k, const GatherRaw& raw, double out[4]) {
-  const bool edge = (j == 0) | (j == 3), odd = k & 1;
-  // level pair exchange: keep my level's half of what I loaded, send the other half to lane ^ 4
+// publish the lane's loads of tracer q in LDS buffer `b` and keep its own 4 values (level pair exchange: keep my level's half
+// of what I loaded, send the other half to lane ^ 4).  Holes publish their copy into their own (unreferenced) entries.
+__device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds& L, int b, int k, const GatherRaw& raw, double v[4]) {
+  const bool odd = k & 1;
+  char* base = reinterpret_cast<char*>(&L.v[b][0][0]);
+  *reinterpret_cast<double2*>(base + R.lw) = raw.w[0];
+  *reinterpret_cast<double2*>(base + R.lw + CL * 8) = raw.w[1];
+  *reinterpret_cast<double2*>(base + R.lwr) = raw.r;
   const double r0 = swz_xor4(odd ? raw.w[0].x : raw.w[0].y), r1 = swz_xor4(odd ? raw.w[1].x : raw.w[1].y);
-  const double v0 = odd ? r0 : raw.w[0].x, v1 = odd ? r1 : raw.w[1].x, v2 = odd ? raw.w[0].y : r0, v3 = odd ? raw.w[1].y : r1;
-  const double s0 = swz_xor4(odd ? raw.g[0].x : raw.g[0].y), s1 = swz_xor4(odd ? raw.g[1].x : raw.g[1].y),
-               s2 = swz_xor4(odd ? raw.g[2].x : raw.g[2].y);
-  // the row's five fetches f0..f4 at this lane's level: even lanes loaded f0,f2,f4, odd lanes f1,f3
-  const double f0 = odd ? s0 : raw.g[0].x, f1 = odd ? raw.g[0].y : s0, f2 = odd ? s1 : raw.g[1].x, f3 = odd ? raw.g[1].y : s1,
-               f4 = odd ? s2 : raw.g[2].x;
+  v[0] = odd ? r0 : raw.w[0].x; v[1] = odd ? r1 : raw.w[1].x; v[2] = odd ? raw.w[0].y : r0; v[3] = odd ? raw.w[1].y : r1;
+  // the values must have left `raw` before the next tracer's loads are issued into it
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+}
+// all LDS writes of the workgroup have landed; the loads of the next tracer stay in flight (no vmcnt wait)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+// the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
+__device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L, int b, int j, const double v[4], double out[4]) {
+  const bool edge = (j == 0) | (j == 3);
+  const char* base = reinterpret_cast<const char*>(&L.v[b][0][0]);
+  const double f0 = *reinterpret_cast<const double*>(base + R.lr[0]), f1 = *reinterpret_cast<const double*>(base + R.lr[1]),
+               f2 = *reinterpret_cast<const double*>(base + R.lr[2]), f3 = *reinterpret_cast<const double*>(base + R.lr[3]),
+               f4 = *reinterpret_cast<const double*>(base + R.lr[4]);
   // quad hand-over: lanes 0 and 3 receive what lanes 1 and 2 fetched for them: quad_perm [1,1,2,2]
   const double d2 = dppq<0xA5>(f2), d3 = dppq<0xA5>(f3), d4 = dppq<0xA5>(f4);
-  double t0 = v0 + f0; t0 = t0 + (edge ? f1 : 0.0); t0 = t0 + (edge ? d2 : 0.0);
-  double t1 = v1 + (edge ? d3 : 0.0);
-  double t2 = v2 + (edge ? d4 : 0.0);
-  double t3 = v3 + (edge ? f2 : f1); t3 = t3 + (edge ? f3 : 0.0); t3 = t3 + (edge ? f4 : 0.0);
+  double t0 = v[0] + f0; t0 = t0 + (edge ? f1 : 0.0); t0 = t0 + (edge ? d2 : 0.0);
+  double t1 = v[1] + (edge ? d3 : 0.0);
+  double t2 = v[2] + (edge ? d4 : 0.0);
+  double t3 = v[3] + (edge ? f2 : f1); t3 = t3 + (edge ? f3 : 0.0); t3 = t3 + (edge ? f4 : 0.0);
   out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
-  // the sums must be complete before the next tracer's loads are issued into `raw`: pin them here (the compiler would
-  // otherwise sink the adds below the loads and keep a second copy of all the values)
-  asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]) : : "memory");
 }
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
 // stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
-__device__ __forceinline__ void store_row_pair(double* __restrict__ row0 /* &T[q][e][j*4][0] */, int k, bool live, const double v[4]) {
+__device__ __forceinline__ void store_row_pair(double* __restrict__ row0 /* &T[q][k/CL][slot][j*4][0] */, int k, bool live, const double v[4]) {
   const bool odd = k & 1;
   const double r0 = swz_xor4(odd ? v[0] : v[2]), r1 = swz_xor4(odd ? v[1] : v[3]);
   if (live) {
-    double* p = row0 + (size_t)(odd ? 2 : 0) * TLEV + (k & ~1);
+    double* p = row0 + (size_t)(odd ? 2 : 0) * CL + ((k & (CL - 1)) & ~1);
     *reinterpret_cast<double2*>(p) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
-    *reinterpret_cast<double2*>(p + TLEV) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
+    *reinterpret_cast<double2*>(p + CL) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
   }
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
 __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* __restrict__ recvbuf, int nlyr_halo, double* __restrict__ dst,
-                              size_t tps, int nelemd) {
+                              Scr S, unsigned halo0 /* entry index of halo column 0 within a chunk */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nq) return;
   const int col = (int)(t / nq), l = (int)(t % nq), q = l / NLEV, k = l - q * NLEV;
-  dst[(size_t)q * tps + (size_t)(nelemd + 1) * 16 * TLEV + (size_t)col * NLEV + k] = recvbuf[(size_t)col * nlyr_halo + l];
+  dst[(size_t)q * S.tps + ((size_t)(k / CL) * S.cse + halo0 + col) * CL + (k % CL)] = recvbuf[(size_t)col * nlyr_halo + l];
+}
+// the all-zero slot of every chunk of every plane (after a caller used the scratch field as a plain buffer)
+__global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned zero0 /* entry index of the zero slot */) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= qsize * NCHUNK * 16 * CL) return;
+  const int w = t % (16 * CL), c = (t / (16 * CL)) % NCHUNK, q = t / (16 * CL * NCHUNK);
+  dst[(size_t)q * S.tps + ((size_t)c * S.cse + zero0) * CL + w] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -284,8 +344,8 @@ __global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* _
 // RHS = rhs_multiplier.  RHS==1 folds in the local min/max update (:781-793).  RHS==2 folds in the second
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
-// GIN: DSS on read (whole-step path).  1: the tracer input is rspheremp*DSS of the previous stage's pre-DSS scratch (passed
-// in Qn0, layout T[q][e][p][k]); 2: the Laplacian input `lap` is (RHS == 2 only).
+// GIN: DSS on read (whole-step path; block = patch x chunk, see above).  1: the tracer input is rspheremp*DSS of the previous
+// stage's pre-DSS scratch (passed in Qn0, scratch layout); 2: the Laplacian input `lap` is (RHS == 2 only).
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
@@ -295,8 +355,18 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
-  const SlabId sid = flat_slab(GA.nwork, GA.order);
-  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
+  __shared__ PatchLds lds_;   // (unused and removed by the compiler when GIN == 0)
+  int e, k, kc, slot;
+  const int j = threadIdx.x & 3;
+  PatchId pid{};
+  if (GIN) {
+    pid = patch_slab(GA);
+    if (!pid.any) return;   // whole block (uniform): before any barrier
+    e = pid.e; kc = pid.k; k = pid.live ? pid.k : NLEV; slot = pid.slot;
+  } else {
+    const SlabId sid = flat_slab(GA.nwork, GA.order);
+    e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
+  }
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
   //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
@@ -341,32 +411,33 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   auto put = [&](const Out& o, int q) {
     // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
     // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
-    store_row_pair(Tout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, o.x);
-    if (k < NLEV && j == 0 && o.ch) { const size_t m = ((size_t)e * qsize + q) * NLEV + k; qmin[m] = o.mn; qmax[m] = o.mx; }
+    store_row_pair(Tout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, o.x);
+    if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
   RowGather RG;
-  GatherRaw graw;                                        // raw own/neighbour values of the gathered input (DSS on read)
+  GatherRaw graw;                                        // raw own / ring loads of the gathered input (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
   const double* gsrc = GIN == 1 ? Qn0 : lap;
   auto fetch = [&](int q) {   // loads only
-    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = ((size_t)e * qsize + q) * NLEV + kc;
+    const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = mm_idx(e, q, kc, qsize);
     if (GIN) gather_issue(RG, GA, gsrc, q, graw);
     if (GIN != 1) load4(Qn0 + so, qnx);
     if (RHS == 2 && GIN != 2) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
   };
-  if (GIN) gather_setup(RG, GA, nelemd, e, j, kc);
+  if (GIN) gather_setup(RG, lds_, GA, pid);
   fetch(0);
+  // Memory schedule with DSS on read: wait for this tracer's own/ring loads -> publish them in LDS -> issue the previous
+  // tracer's stores and the next tracer's loads -> workgroup barrier -> neighbour values from LDS -> compute.
   auto step = [&](int q, const Out* prev, Out& cur) {
-    double qn[4], ls[4] = {0, 0, 0, 0}, minp = minx, maxp = maxx;
-    if (GIN == 1) gather_sum(RG, j, kc, graw, qn);
-    else {
+    double qn[4], ls[4] = {0, 0, 0, 0}, own[4], minp = minx, maxp = maxx;
+    if (GIN) gather_publish(RG, lds_, q & 1, kc, graw, own);
+    if (GIN != 1) {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
       asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
     }
-    if (RHS == 2 && GIN == 2) gather_sum(RG, j, kc, graw, ls);
-    else if (RHS >= 2) {
+    if (RHS >= 2 && GIN != 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) ls[i] = lsx[i];
       asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]) : : "memory");
@@ -376,6 +447,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     if (prev) put(*prev, q - 1);
     fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
+    if (GIN) {
+      lds_barrier();
+      gather_sum(RG, lds_, q & 1, j, own, GIN == 1 ? qn : ls);
+    }
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
       laplace_lean_row(D, L, ls, bih);
@@ -438,16 +513,26 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // ---------------------------------------------------------------------------------------------------
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
-// GIN == 1 (whole-step path): Qn0 is the stage-2 pre-DSS scratch T[q][e][p][k]; the DSS'd Qdp is assembled on read and
-// also stored to Qout (stage 3 reads it again in k_advance).
+// GIN == 1 (whole-step path; block = patch x chunk): Qn0 is the stage-2 pre-DSS scratch; the DSS'd Qdp is assembled on read
+// and also stored to Qout (stage 3 reads it again in k_advance).
 template <int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax, double* __restrict__ Qout,
                                                        GatherArgs GA) {
-  const SlabId sid = flat_slab(GA.nwork, GA.order);
-  const int e = sid.e, k = sid.live ? sid.k : NLEV, j = threadIdx.x & 3, kc = sid.k;
+  __shared__ PatchLds lds_;
+  int e, k, kc, slot;
+  const int j = threadIdx.x & 3;
+  PatchId pid{};
+  if (GIN) {
+    pid = patch_slab(GA);
+    if (!pid.any) return;   // whole block (uniform): before any barrier
+    e = pid.e; kc = pid.k; k = pid.live ? pid.k : NLEV; slot = pid.slot;
+  } else {
+    const SlabId sid = flat_slab(GA.nwork, GA.order);
+    e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
+  }
   LapGeo L;
   {
     RowGeo g;
@@ -461,7 +546,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   RowGather RG;
   GatherRaw graw;
-  if (GIN) { gather_setup(RG, GA, nelemd, e, j, kc); gather_issue(RG, GA, Qn0, 0, graw); }
+  if (GIN) { gather_setup(RG, lds_, GA, pid); gather_issue(RG, GA, Qn0, 0, graw); }
   if (!GIN) {
     for (int q = 0; q < qsize; q++) {
       const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
@@ -472,30 +557,33 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
       double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
       double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
       laplace_lean_row(D, L, x, l1);
-      store_row_pair(Bout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, l1);   // scratch layout, as T
-      if (k < NLEV && j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = mn; qmax[((size_t)e * qsize + q) * NLEV + k] = mx; }
+      store_row_pair(Bout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, l1);   // scratch layout, as T
+      if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = mn; qmax[mm_idx(e, q, k, qsize)] = mx; }
     }
     return;
   }
   // DSS on read.  Memory schedule of one tracer step (gfx950: one counter for loads and stores, which return out of order
   // between the two kinds, so a wait for loads also drains every store issued before it; and a store's data registers may
   // not be overwritten until it has completed):
-  //   wait for this tracer's gather -> sum -> issue the PREVIOUS tracer's stores -> issue the NEXT tracer's gather -> compute.
+  //   wait for this tracer's own/ring loads -> publish in LDS -> issue the PREVIOUS tracer's stores -> issue the NEXT tracer's
+  //   loads -> workgroup barrier -> neighbour values from LDS, sum -> compute.
   // The results go to a second register set (A/B alternate), so that the stores issued at the top of a step drain during
   // the whole step and nothing waits for them.
   struct Out { double q[4], l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
     if (k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
-    store_row_pair(Bout + t_idx(GA.tps, q, e, j * 4, 0), kc, k < NLEV, o.l);
-    if (k < NLEV && j == 0) { qmin[((size_t)e * qsize + q) * NLEV + k] = o.mn; qmax[((size_t)e * qsize + q) * NLEV + k] = o.mx; }
+    store_row_pair(Bout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, o.l);
+    if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = o.mn; qmax[mm_idx(e, q, k, qsize)] = o.mx; }
   };
   auto step = [&](int q, const Out* prev, Out& cur) {
-    double x[4];
-    gather_sum(RG, j, kc, graw, x);
+    double x[4], own[4];
+    gather_publish(RG, lds_, q & 1, kc, graw, own);
     __builtin_amdgcn_sched_barrier(0);
     if (prev) put(*prev, q - 1);
     gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, graw);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    gather_sum(RG, lds_, q & 1, j, own, x);
 #pragma unroll
     for (int i = 0; i < 4; i++) { cur.q[i] = x[i]; x[i] = x[i] * dpk[i]; }
     cur.mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
@@ -517,10 +605,9 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 // so results do not depend on how elements are distributed over GPUs.
 //   tab[e][16][3] = {source element (>=0 local, -1 none, <=-2 remote column -(v+2)), source point}
 //   remote values come from recvbuf[col][nlyr_halo] (layer = q*NLEV+k, the reference's message layout).
-// Tracer-field DSS: source in the level-fastest scratch layout src[q][e][p][k] written by k_advance/k_lap1, destination in the
+// Tracer-field DSS: source in the scratch layout src[q][kc][slot][p][kk] written by k_advance/k_lap1, destination in the
 // standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
 // k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
-// Work items are ordered tracer-chunk-major and the 8 XCDs each walk a contiguous range of elements (see k_dss).
 // MODE 0: dst = rspheremp * DSS(src)                                   (prim_advection_mod.F90:929-960)
 // MODE 1: ... fused with qdp_time_avg: dst = (Qn0 + 2*that)/3         (:645-662)
 // Lane mapping shared by the tracer DSS kernels: work = (tracer chunk, XCD range of elements, flattened (element slot,
@@ -540,96 +627,68 @@ __device__ __forceinline__ DssLane dss_lane(int nelemd) {
   l.qc = it / B8; l.r = g - idx * UNITS; l.slot = xcd * S8 + idx; l.live = idx < S8 && l.slot < nelemd;
   return l;
 }
-// Tracer DSS pass: every lane handles TWO consecutive levels of one row, so that each own/neighbour access is a 16-byte
-// load (the level-fastest source makes the level pair contiguous).  A one-level-per-lane version spent as much time
-// issuing its 12 eight-byte loads per tracer as moving the data (a variant whose gathers all hit the lane's own element
-// in L1 was as slow as the real one).  Only 8 of the 16x3 table slots can be populated for a row: points i=0 and i=3 take
-// up to 3 contributions (two edges + a corner), i=1,2 at most one.  All gathers are issued unconditionally (an empty slot
-// re-reads the lane's own value and is weighted 0) so that the 8 loads are in flight together -- a load inside a
-// divergent branch is waited for on the spot, which serialises 8 memory latencies per tracer.
-constexpr int DSS2_THREADS = DSS_FLAT_THREADS;
-constexpr int DSS2_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs x 4 rows
-inline int dss2_blocks_per_xcd(int nelemd) { return dss_blocks_per_xcd<DSS2_UNITS>(nelemd); }
+// Tracer DSS pass (per-stage API, and the last pass of the whole-step path): block = (patch, chunk) exactly like the
+// DSS-on-read slab kernels -- own points and the patch's halo ring are loaded once per tracer, published in LDS, and the
+// neighbour contributions are LDS reads; remote contributions sit in the halo columns of the scratch planes (k_unpack_halo).
+// mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
+// next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
 template <int MODE>
-__global__ __launch_bounds__(DSS2_THREADS) void k_dss_t2(int nelemd, int qsize, int qb, const int2* __restrict__ tab,
-                                                         const double* __restrict__ rspheremp, const double* __restrict__ src,
-                                                         double* __restrict__ dst, const double* __restrict__ Qn0,
-                                                         const double* __restrict__ recvbuf, int nlyr_halo,
-                                                         const int* __restrict__ order, const double* __restrict__ dpnext,
-                                                         double* __restrict__ mn_out, double* __restrict__ mx_out, size_t tps) {
-  // mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
-  // next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
-  const DssLane ln = dss_lane<DSS2_UNITS>(nelemd);
-  if (!ln.live) return;
-  const int slot = ln.slot, r = ln.r, qc = ln.qc;
-  const int e = order[slot];
-  const int k0 = (r >> 2) * 2, j = r & 3;            // levels k0, k0+1
-  constexpr int NS = 8;
-  const int si[NS] = {0, 0, 0, 1, 2, 3, 3, 3}, sc[NS] = {0, 1, 2, 0, 0, 0, 1, 2};
-  const double* gp[NS];
-  unsigned gvalid = 0, gremote = 0;
-  const int q0 = qc * qb;
-  const double* own0 = src + t_idx(tps, q0, e, j * 4, k0);
-  int2 tt[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) tt[s] = tab[((size_t)e * 16 + j * 4 + si[s]) * 3 + sc[s]];
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const int2 t = tt[s];
-    if (t.x >= 0) { gp[s] = src + t_idx(tps, q0, t.x, t.y, k0); gvalid |= 1u << s; }
-    else if (t.x <= -2) { gp[s] = recvbuf + (size_t)(-(t.x + 2)) * nlyr_halo + (size_t)q0 * NLEV + k0; gvalid |= 1u << s; gremote |= 1u << s; }
-    else gp[s] = own0;
-  }
-  double rs[4];
-  load4(rspheremp + (size_t)e * 16 + j * 4, rs);
-  double dn0[4] = {1, 1, 1, 1}, dn1[4] = {1, 1, 1, 1};
-  if (MODE == 1 && mn_out) {
-    load4(dpnext + ((size_t)e * NLEV + k0) * 16 + j * 4, dn0);
-    load4(dpnext + ((size_t)e * NLEV + k0 + 1) * 16 + j * 4, dn1);
-  }
-  const int q1 = min(qsize, (qc + 1) * qb);
-  for (int q = q0; q < q1; q++) {
-    const size_t dq = (size_t)(q - q0);
-    double2 v[4], a[NS];
-#pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = *reinterpret_cast<const double2*>(own0 + dq * tps + (size_t)i * TLEV);
-#pragma unroll
-    for (int s = 0; s < NS; s++) a[s] = make_double2(0.0, 0.0);
-#pragma unroll
-    for (int s = 0; s < NS; s++)
-      if (gvalid & (1u << s)) a[s] = *reinterpret_cast<const double2*>(gp[s] + dq * ((gremote & (1u << s)) ? (size_t)NLEV : tps));
-    // the reference's order: edge contributions (S, E, N, W) first, then the corner; an empty slot adds +0.0
-#define ADD2(vi, as) do { vi.x = vi.x + as.x; vi.y = vi.y + as.y; } while (0)
-    ADD2(v[0], a[0]); ADD2(v[0], a[1]); ADD2(v[0], a[2]);
-    ADD2(v[1], a[3]);
-    ADD2(v[2], a[4]);
-    ADD2(v[3], a[5]); ADD2(v[3], a[6]); ADD2(v[3], a[7]);
-#undef ADD2
-    double o0[4], o1[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { o0[i] = rs[i] * v[i].x; o1[i] = rs[i] * v[i].y; }
-    const size_t off = (((size_t)e * qsize + q) * NLEV + k0) * 16 + j * 4;
+__global__ __launch_bounds__(FLAT_THREADS) void k_dss_patch(int qsize, const double* __restrict__ src, double* __restrict__ dst,
+                                                            const double* __restrict__ Qn0, const double* __restrict__ dpnext,
+                                                            double* __restrict__ mn_out, double* __restrict__ mx_out, GatherArgs GA) {
+  __shared__ PatchLds lds_;
+  const PatchId pid = patch_slab(GA);
+  if (!pid.any) return;   // whole block (uniform): before any barrier
+  const int e = pid.e, kc = pid.k, k = pid.live ? pid.k : NLEV, j = pid.j;
+  RowGather RG;
+  GatherRaw graw;
+  gather_setup(RG, lds_, GA, pid);
+  double dn[4] = {1, 1, 1, 1}, q0x[4] = {0, 0, 0, 0};
+  if (MODE == 1 && mn_out) load4(dpnext + ((size_t)e * NLEV + kc) * 16 + j * 4, dn);
+  auto fetch = [&](int q) {
+    gather_issue(RG, GA, src, q, graw);
+    if (MODE == 1) load4(Qn0 + (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, q0x);
+  };
+  struct Out { double x[4], mn, mx; };
+  auto put = [&](const Out& o, int q) {
+    if (k < NLEV) {
+      store4(dst + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.x);
+      if (MODE == 1 && mn_out && j == 0) { const size_t mi = mm_idx(e, q, k, qsize); mn_out[mi] = o.mn; mx_out[mi] = o.mx; }
+    }
+  };
+  // wait for this tracer's loads -> publish in LDS -> issue the PREVIOUS tracer's stores and the NEXT tracer's loads ->
+  // workgroup barrier -> neighbour values from LDS -> sum (results alternate between two register sets, see k_lap1)
+  auto step = [&](int q, const Out* prev, Out& cur) {
+    double own[4], qa[4], x[4];
+    gather_publish(RG, lds_, q & 1, kc, graw, own);
     if (MODE == 1) {
-      double q0v[4], q1v[4];
-      load4(Qn0 + off, q0v); load4(Qn0 + off + 16, q1v);
 #pragma unroll
-      for (int i = 0; i < 4; i++) { o0[i] = (q0v[i] + 2 * o0[i]) / 3; o1[i] = (q1v[i] + 2 * o1[i]) / 3; }
+      for (int i = 0; i < 4; i++) qa[i] = q0x[i];
+      asm volatile("" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]) : : "memory");
     }
-    store4(dst + off, o0);
-    store4(dst + off + 16, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prev) put(*prev, q - 1);
+    fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();
+    gather_sum(RG, lds_, q & 1, j, own, x);
+#pragma unroll
+    for (int i = 0; i < 4; i++) cur.x[i] = MODE == 1 ? (qa[i] + 2 * x[i]) / 3 : x[i];   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
     if (MODE == 1 && mn_out) {
-      double x0[4], x1[4];
+      double y[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) { x0[i] = o0[i] / dn0[i]; x1[i] = o1[i] / dn1[i]; }
-      const double mn0 = quad_min(fmin(fmin(x0[0], x0[1]), fmin(x0[2], x0[3]))), mx0 = quad_max(fmax(fmax(x0[0], x0[1]), fmax(x0[2], x0[3])));
-      const double mn1 = quad_min(fmin(fmin(x1[0], x1[1]), fmin(x1[2], x1[3]))), mx1 = quad_max(fmax(fmax(x1[0], x1[1]), fmax(x1[2], x1[3])));
-      if (j == 0) {
-        const size_t mi = ((size_t)e * qsize + q) * NLEV + k0;
-        *reinterpret_cast<double2*>(mn_out + mi) = make_double2(mn0, mn1);   // k0 is even: 16-byte aligned
-        *reinterpret_cast<double2*>(mx_out + mi) = make_double2(mx0, mx1);
-      }
+      for (int i = 0; i < 4; i++) y[i] = cur.x[i] / dn[i];
+      cur.mn = quad_min(fmin(fmin(y[0], y[1]), fmin(y[2], y[3])));
+      cur.mx = quad_max(fmax(fmax(y[0], y[1]), fmax(y[2], y[3])));
     }
-  }
+  };
+  fetch(0);
+  Out A, B;
+  step(0, nullptr, A);
+  int q = 1;
+  for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
+  if (q < qsize) { step(q, &A, B); put(B, q); }
+  else put(A, q - 1);
 }
 
 // DSS of one level field (divdp_proj, eta_dot_dpdn(1:nlev), omega_p): dst = rspheremp * DSS(spheremp * src)
@@ -698,13 +757,13 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const 
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
-                       size_t tps /* > 0: src is a scratch field (plane stride tps) instead of [e][lyr][p] */,
+                       Scr S /* S.tps > 0: src is a scratch field and send_src holds slots, instead of [e][lyr][p] and elements */,
                        int src_lyr /* layers per element of a plain src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nlyr) return;
   int col = (int)(t / nlyr), l = (int)(t % nlyr);
   int2 s = send_src[col];
-  double a = tps ? src[t_idx(tps, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * src_lyr + l) * 16 + s.y];
+  double a = S.tps ? src[t_idx(S, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * src_lyr + l) * 16 + s.y];
   if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
   sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
 }
@@ -737,6 +796,7 @@ __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0
 // in-place update never overtakes the reads).
 constexpr int REMAP_THREADS = 576;
 constexpr int REMAP_PF = 8;  // column loads kept in flight per thread
+static_assert(REMAP_PF % CL == 0, "a block of REMAP_PF levels holds whole chunks of the bounds layout");
 struct RemapLds {
   double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
   double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
@@ -831,7 +891,7 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
         double mn = x, mx = x;
         mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
         mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-        if (p == 0) { mn_out[((size_t)e * qsize + q) * NLEV + k - 1] = mn; mx_out[((size_t)e * qsize + q) * NLEV + k - 1] = mx; }
+        if (p == 0) { mn_out[mm_idx(e, q, k - 1, qsize)] = mn; mx_out[mm_idx(e, q, k - 1, qsize)] = mx; }
       }
     }
 #undef TSE_READ_NEXT
@@ -862,8 +922,9 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       const int qq = on ? q0 + t : qsize - 1;
       col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
       colw[t] = on ? col[t] : sink + p;
-      mnp[t] = on && mn_out ? mn_out + ((size_t)e * qsize + qq) * NLEV : sink + NLEV * 16;
-      mxp[t] = on && mn_out ? mx_out + ((size_t)e * qsize + qq) * NLEV : sink + NLEV * 17;
+      // bounds of tracer qq at level k: base[(k / CL) * qsize * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
+      mnp[t] = on && mn_out ? mn_out + mm_idx(e, qq, 0, qsize) : sink + NLEV * 16;
+      mxp[t] = on && mn_out ? mx_out + mm_idx(e, qq, 0, qsize) : sink + NLEV * 16 + (size_t)NLEV * qsize;
     }
     double pf[NT][REMAP_PF];
     double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
@@ -940,7 +1001,8 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
           double mn = x, mx = x;
           mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
           mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-          mnp[t][k - 1] = mn; mxp[t][k - 1] = mx;   // every lane of the row holds the row's result
+          const size_t mo = (size_t)((kb + sl) / CL) * qsize * CL + (sl % CL);   // kb is a multiple of 8
+          mnp[t][mo] = mn; mxp[t][mo] = mx;   // every lane of the row holds the row's result
         }
         masso[t] = mo1;
         ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
