@@ -100,6 +100,11 @@ int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
 /* number of local elements that touch another rank (computed first in every stage) and that do not */
 int tse_boundary_layout(tse_ctx *ctx, int *n_boundary, int *n_interior);
 
+/* Optional: declare the host's element array (elem(1) .. elem(nelemd), contiguous, alive until tse_finalize).  It is page-locked
+ * once and every later field copy whose host side lies inside it is a single 2-D DMA with pitch = sizeof(element_t) straight
+ * from/to elem(:); host pointers outside a registered range are staged through the library's own pinned buffers.  Returns 0 also
+ * when the range is not registered (larger than TSE_PIN_LIMIT_GB, default 64, or refused by the driver). */
+int tse_host_register(tse_ctx *ctx, void *base, size_t bytes);
 /* elem(ie)%state%Qdp(np,np,nlev,qsize_d,2) <-> device, time level nt (1|2); qsize_d = host array extent */
 int tse_copy_qdp_h2d(tse_ctx *ctx, const double *qdp_elem1, size_t elem_stride, int qsize_d, int nt);
 int tse_copy_qdp_d2h(tse_ctx *ctx, double *qdp_elem1, size_t elem_stride, int qsize_d, int nt);

@@ -50,7 +50,7 @@ program ref_harness
 #ifdef TSE_HIP
   ! built by transport_se_amd/fortran/Makefile: prim_advection_mod is the reference's file compiled with
   ! -DUSE_CUDA_FORTRAN=1, and `cuda_mod` is transport_se_amd/fortran/cuda_mod_hip.F90 (the HIP library's Fortran seam)
-  use cuda_mod,           only : cuda_mod_init, copy_qdp_h2d, copy_qdp_d2h, advec_tracers_remap_rk2_hip
+  use cuda_mod,           only : cuda_mod_init, copy_qdp_h2d, copy_qdp_d2h, advec_tracers_remap_rk2_hip, hip_seam_report
 #endif
   implicit none
 #include <mpif.h>
@@ -239,6 +239,9 @@ program ref_harness
      write(*,'(a,es14.6)') ' ref_harness: tracer-DOF-steps/s = ', &
           dble(nelem)*np*np*nlev*qsize*istep / (dble(c1-c0)/dble(crate))
   endif
+#ifdef TSE_HIP
+  if (par%masterproc) call hip_seam_report(istep)
+#endif
   call haltmp('ref_harness done')
 
 contains

@@ -11,6 +11,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,8 +80,10 @@ struct tse_ctx {
   // dcmip
   int dcmip_test = 0;
   double *lat = nullptr, *lon = nullptr, *zm = nullptr, *zi = nullptr, *pint = nullptr, *dph = nullptr;
-  // staging + timing
-  std::vector<double> hstage;
+  // page-locked range of the host's elem(:) (host_pin) + timing
+  uintptr_t pin_lo = 0, pin_hi = 0;            // host range registered with tse_host_register
+  double* stage[2] = {nullptr, nullptr};       // page-locked staging buffers for every other host pointer
+  hipEvent_t stage_ev[2] = {nullptr, nullptr};
   bool timing = false;
   std::map<std::string, KTimer> timers;
   struct Pending { const char* name; hipEvent_t a, b; };
@@ -372,7 +375,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
             if (it == ring.end()) {
               if ((int)ring.size() >= NRMAX) return fail("tse_init: halo ring of patch %d exceeds %d entries", pi, NRMAX);
               it = ring.emplace(key, (int)ring.size()).first;
-              pring[(size_t)pi * NRMAX + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + t.y : c->halo0() + (unsigned)(-(t.x + 2));
+              pring[(size_t)pi * NRMAX + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + ppos(t.y) : c->halo0() + (unsigned)(-(t.x + 2));
             }
             ent = (unsigned short)(PS * 16 + it->second);
           }
@@ -381,7 +384,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
       }
     }
     std::vector<int2> send_s(send_src);
-    for (int2& t : send_s) t.x = slot_of[t.x];
+    for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(t.y); }   // {slot, position within the slot}
     // rank-boundary patches first, as the elements above
     std::vector<int> pb, pin;
     {
@@ -462,6 +465,8 @@ void tse_finalize(tse_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+  if (c->pin_hi) (void)hipHostUnregister((void*)c->pin_lo);
+  for (int i = 0; i < 2; i++) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
@@ -521,42 +526,88 @@ int tse_comm_info(tse_ctx* c, int* rank, int* nranks) {
 }
 
 // ---- host <-> device copies ---------------------------------------------------------------------
+// The host keeps elem(:) as a strided array of structures.  A host that has declared that array with tse_host_register
+// (page-locked once, for the life of the context) gets every field copy as ONE 2-D DMA straight between elem(:) and the dense
+// device array (row = one element's field, pitch = sizeof(element_t)): no staging copy at all.  Any other host pointer --
+// temporaries, numpy arrays -- goes through the library's own page-locked staging buffers, two of them, so that packing the
+// next block of elements overlaps the DMA of the previous one.  (Page-locking memory the caller may free behind the
+// library's back is not safe, so it is never done implicitly.)
+int tse_host_register(tse_ctx* c, void* base, size_t bytes) {
+  static const double limit_gb = getenv("TSE_PIN_LIMIT_GB") ? atof(getenv("TSE_PIN_LIMIT_GB")) : 64.0;
+  if (!base || !bytes) return fail("tse_host_register: null range");
+  if (c->pin_hi) return fail("tse_host_register: a host range is already registered");
+  if ((double)bytes > limit_gb * 1073741824.0) return 0;   // staged copies (TSE_PIN_LIMIT_GB raises the limit)
+  if (hipHostRegister(base, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }   // not fatal: staged copies
+  c->pin_lo = (uintptr_t)base; c->pin_hi = c->pin_lo + bytes;
+  return 0;
+}
+static const size_t STAGE_BYTES = (size_t)32 << 20;
+// `cnt` doubles per element between host (element stride `stride` bytes) and a dense device array [nelemd][cnt_dev]; asynchronous
+// on the compute stream for registered host memory, complete on return otherwise
+static int copy_field(tse_ctx* c, double* dev, size_t cnt_dev, void* host, size_t stride, size_t cnt, bool to_device) {
+  if (!host) return 0;
+  const int n = c->nelemd;
+  if (stride < cnt * 8 && n > 1) return fail("field copy: element stride %zu smaller than the field (%zu bytes)", stride, cnt * 8);
+  const uintptr_t a = (uintptr_t)host, b = a + (size_t)(n - 1) * stride + cnt * 8;
+  if (c->pin_hi && a >= c->pin_lo && b <= c->pin_hi) {
+    const size_t pitch = n > 1 ? stride : cnt * 8;
+    if (to_device) HIPCHK(hipMemcpy2DAsync(dev, cnt_dev * 8, host, pitch, cnt * 8, n, hipMemcpyHostToDevice, c->stream));
+    else HIPCHK(hipMemcpy2DAsync(host, pitch, dev, cnt_dev * 8, cnt * 8, n, hipMemcpyDeviceToHost, c->stream));
+    return 0;
+  }
+  if (!c->stage[0]) {
+    HIPCHK(hipHostMalloc((void**)&c->stage[0], STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&c->stage[1], STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->stage_ev[1], hipEventDisableTiming));
+  }
+  const int per = (int)std::max<size_t>(1, STAGE_BYTES / (cnt * 8));   // elements per block
+  if (to_device) {
+    int bi = 0;
+    for (int e0 = 0; e0 < n; e0 += per, bi ^= 1) {
+      const int m = std::min(per, n - e0);
+      HIPCHK(hipEventSynchronize(c->stage_ev[bi]));   // the DMA that last read this buffer
+      for (int e = 0; e < m; e++) memcpy(c->stage[bi] + (size_t)e * cnt, (const char*)host + (size_t)(e0 + e) * stride, cnt * 8);
+      HIPCHK(hipMemcpy2DAsync(dev + (size_t)e0 * cnt_dev, cnt_dev * 8, c->stage[bi], cnt * 8, cnt * 8, m, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(hipEventRecord(c->stage_ev[bi], c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+  } else {
+    int bi = 0, pend_e0 = -1, pend_m = 0;
+    auto drain = [&](int buf, int e0, int m) {
+      (void)hipEventSynchronize(c->stage_ev[buf]);
+      for (int e = 0; e < m; e++) memcpy((char*)host + (size_t)(e0 + e) * stride, c->stage[buf] + (size_t)e * cnt, cnt * 8);
+    };
+    for (int e0 = 0; e0 < n; e0 += per, bi ^= 1) {
+      const int m = std::min(per, n - e0);
+      HIPCHK(hipMemcpy2DAsync(c->stage[bi], cnt * 8, dev + (size_t)e0 * cnt_dev, cnt_dev * 8, cnt * 8, m, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipEventRecord(c->stage_ev[bi], c->stream));
+      if (pend_e0 >= 0) drain(bi ^ 1, pend_e0, pend_m);   // unpack the previous block while this one travels
+      pend_e0 = e0; pend_m = m;
+    }
+    if (pend_e0 >= 0) drain(bi ^ 1, pend_e0, pend_m);
+  }
+  return 0;
+}
 int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, int nt) {
   c->mm_valid = 0;
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_h2d: nt=%d qsize_d=%d", nt, qsize_d);
-  const size_t per = (size_t)c->qsize * NLEV * 16;
-  c->hstage.resize((size_t)c->nelemd * per);
-  for (int e = 0; e < c->nelemd; e++)  // Qdp(np,np,nlev,qsize_d,2): time level nt starts qsize_d*nlev*16 doubles in
-    memcpy(&c->hstage[(size_t)e * per], (const char*)q1 + (size_t)e * stride + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, per * 8);
-  HIPCHK(hipMemcpyAsync(c->qdp + (size_t)(nt - 1) * c->trc(), c->hstage.data(), c->hstage.size() * 8, hipMemcpyHostToDevice, c->stream));
+  const size_t per = (size_t)c->qsize * NLEV * 16;   // Qdp(np,np,nlev,qsize_d,2): time level nt starts qsize_d*nlev*16 doubles in
+  if (copy_field(c, c->qdp + (size_t)(nt - 1) * c->trc(), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, true)) return 1;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int tse_copy_qdp_d2h(tse_ctx* c, double* q1, size_t stride, int qsize_d, int nt) {
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_d2h: nt=%d qsize_d=%d", nt, qsize_d);
   const size_t per = (size_t)c->qsize * NLEV * 16;
-  c->hstage.resize((size_t)c->nelemd * per);
-  HIPCHK(hipMemcpyAsync(c->hstage.data(), c->qdp + (size_t)(nt - 1) * c->trc(), c->hstage.size() * 8, hipMemcpyDeviceToHost, c->stream));
+  if (copy_field(c, c->qdp + (size_t)(nt - 1) * c->trc(), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, false)) return 1;
   HIPCHK(hipStreamSynchronize(c->stream));
-  for (int e = 0; e < c->nelemd; e++)
-    memcpy((char*)q1 + (size_t)e * stride + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, &c->hstage[(size_t)e * per], per * 8);
   return 0;
 }
 static int put_level(tse_ctx* c, double* dev, const double* host, size_t stride, size_t cnt_dev, size_t cnt_host) {
-  if (!host) return 0;
-  c->hstage.assign((size_t)c->nelemd * cnt_dev, 0.0);
-  for (int e = 0; e < c->nelemd; e++) memcpy(&c->hstage[(size_t)e * cnt_dev], (const char*)host + (size_t)e * stride, std::min(cnt_dev, cnt_host) * 8);
-  HIPCHK(hipMemcpyAsync(dev, c->hstage.data(), c->hstage.size() * 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  return 0;
+  return copy_field(c, dev, cnt_dev, (void*)host, stride, std::min(cnt_dev, cnt_host), true);
 }
 static int get_level(tse_ctx* c, const double* dev, double* host, size_t stride, size_t cnt_dev, size_t cnt_host) {
-  if (!host) return 0;
-  c->hstage.resize((size_t)c->nelemd * cnt_dev);
-  HIPCHK(hipMemcpyAsync(c->hstage.data(), dev, c->hstage.size() * 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
-  for (int e = 0; e < c->nelemd; e++) memcpy((char*)host + (size_t)e * stride, &c->hstage[(size_t)e * cnt_dev], std::min(cnt_dev, cnt_host) * 8);
-  return 0;
+  return copy_field(c, (double*)dev, cnt_dev, host, stride, std::min(cnt_dev, cnt_host), false);
 }
 int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, size_t s1, const double* eta, size_t s2,
                     const double* omega_p, size_t s3) {
@@ -566,11 +617,13 @@ int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, 
   if (put_level(c, c->dp, dp, s1, NLEV * 16, NLEV * 16)) return 1;
   if (put_level(c, c->eta, eta, s2, NLEVP * 16, NLEVP * 16)) return 1;
   if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
+  HIPCHK(hipStreamSynchronize(c->stream));   // the caller may reuse its arrays
   return 0;
 }
 int tse_set_divdp(tse_ctx* c, const double* divdp, size_t s0, const double* divdp_proj, size_t s1) {
   if (put_level(c, c->divdp, divdp, s0, NLEV * 16, NLEV * 16)) return 1;
   if (put_level(c, c->divdp_proj, divdp_proj, s1, NLEV * 16, NLEV * 16)) return 1;
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size_t s2, double* omega_p, size_t s3, double* divdp,
@@ -581,6 +634,7 @@ int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size
   if (get_level(c, c->divdp, divdp, s4, NLEV * 16, NLEV * 16)) return 1;
   if (get_level(c, c->dp3d, dp3d, s5, NLEV * 16, NLEV * 16)) return 1;
   if (get_level(c, c->ps_v, ps_v, s6, 16, 16)) return 1;
+  HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {

@@ -3,7 +3,7 @@
 // HBM layout (all fp64, point index p = j*4+i fastest):
 //   tracer fields  Qdp[tl][e][q][k][p]
 //   pre-DSS scratch T, B: tracer-major planes; inside a plane the 72 levels are cut into NCHUNK chunks of CL = 4 levels and
-//                  a chunk holds, level fastest, T[q][kc][slot][p][kk]: the element slots (elements regrouped into
+//                  a chunk holds, level fastest, T[q][kc][slot][pos(p)][kk] (points perimeter first): the element slots (elements regrouped into
 //                  patches of <= 16 neighbouring elements, tse_api.hip), then one all-zero slot (target of empty DSS
 //                  contributions), then the received halo columns [col][kk].  Plane stride `tps` doubles, `cse` entries
 //                  (points / halo columns) per chunk.  A plane is < 4 GB, so the DSS-on-read kernels address it with one
@@ -33,9 +33,14 @@ static_assert(NLEV % CL == 0 && CL % 2 == 0, "chunks hold whole level pairs");
 constexpr int PS = 16;        // element slots per patch
 constexpr int NRMAX = 128;    // halo-ring entries of a patch (a full 4x4 patch has 92; tse_api.hip splits patches that need more)
 struct Scr { size_t tps; unsigned cse; };   // plane stride (doubles), entries per chunk
-// element index of T[q][k / CL][slot][p][k % CL]
-__device__ __forceinline__ size_t t_idx(Scr S, int q, int slot, int p, int k) {
-  return (size_t)q * S.tps + ((size_t)(k / CL) * S.cse + (size_t)slot * 16 + p) * CL + (k % CL);
+// Inside a slot the 16 points are stored perimeter first -- S edge (points 0,1,2,3), E (7,11,15), N (14,13,12), W (8,4), then the
+// interior (5,6,9,10) -- so that the 4 points of an edge, which is what a neighbouring patch's halo ring reads, are 128
+// contiguous bytes (1-2 lines) instead of 32 bytes out of each of 4 lines.  PPOS: nibble p = position of point p.
+constexpr unsigned long long PPOS = 0x67895FEA4DCB3210ULL;
+__host__ __device__ __forceinline__ int ppos(int p) { return (int)((PPOS >> (4 * p)) & 15ull); }
+// element index of T[q][k / CL][slot][pos][k % CL], pos = ppos(point)
+__device__ __forceinline__ size_t t_idx(Scr S, int q, int slot, int pos, int k) {
+  return (size_t)q * S.tps + ((size_t)(k / CL) * S.cse + (size_t)slot * 16 + pos) * CL + (k % CL);
 }
 // qmin/qmax(k,q,e) of prim_advection_mod (:459) in the device layout [e][k / CL][q][k % CL]
 __device__ __forceinline__ size_t mm_idx(int e, int q, int k, int qsize) { return (((size_t)e * NCHUNK + k / CL) * qsize + q) * CL + (k % CL); }
@@ -239,7 +244,7 @@ __device__ __forceinline__ PatchId patch_slab(const GatherArgs& A) {
 
 struct GatherRaw { double2 w[2], r; };   // the lane's two own loads and its ring load
 struct RowGather {
-  unsigned own;        // plane-relative byte offset of T[.][kc][slot][j*4 + (odd ? 2 : 0)][kk & ~1]; the second own load is CL*8 further
+  unsigned own, own1;  // plane-relative byte offsets of T[.][kc][slot][pos(j*4 + (odd ? 2 : 0) + {0,1})][kk & ~1]
   unsigned ring;       // plane-relative byte offset of the lane's half of a ring entry
   unsigned lw, lwr;    // LDS byte offsets (buffer 0) where the lane publishes its first own load / its ring load
   unsigned lr[5];      // LDS byte offsets (buffer 0) of the lane's five neighbour values
@@ -256,7 +261,8 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds& L, const Ga
   const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
   const unsigned chunk0 = (unsigned)kc * A.S.cse;                       // first entry of the chunk
   const int p0 = j * 4 + (odd ? 2 : 0);
-  R.own = ((chunk0 + (unsigned)P.slot * 16 + p0) * CL + (kk & ~1)) * 8u;
+  R.own = ((chunk0 + (unsigned)P.slot * 16 + ppos(p0)) * CL + (kk & ~1)) * 8u;
+  R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(p0 + 1)) * CL + (kk & ~1)) * 8u;
   R.lw = (unsigned)((sl * 16 + p0) * CL + (kk & ~1)) * 8u;
   unsigned short le[5];
 #pragma unroll
@@ -274,10 +280,10 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds& L, const Ga
 // The empty asm keeps the offsets opaque inside the tracer loop: otherwise their zero-extension is hoisted out of the loop
 // (two registers per offset) and the loads fall back from "SGPR base + 32-bit VGPR offset" to 64-bit VALU address math.
 __device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, const double* __restrict__ src, int q, GatherRaw& raw) {
-  asm volatile("" : "+v"(R.own), "+v"(R.ring));
+  asm volatile("" : "+v"(R.own), "+v"(R.own1), "+v"(R.ring));
   const char* pq = reinterpret_cast<const char*>(src + (size_t)q * A.S.tps);   // wave-uniform
   raw.w[0] = *reinterpret_cast<const double2*>(pq + R.own);
-  raw.w[1] = *reinterpret_cast<const double2*>(pq + (R.own + (unsigned)(CL * 8)));
+  raw.w[1] = *reinterpret_cast<const double2*>(pq + R.own1);
   raw.r = *reinterpret_cast<const double2*>(pq + R.ring);
 }
 // publish the lane's loads of tracer q in LDS buffer `b` and keep its own 4 values (level pair exchange: keep my level's half
@@ -313,13 +319,18 @@ __device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
 // stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
-__device__ __forceinline__ void store_row_pair(double* __restrict__ row0 /* &T[q][k/CL][slot][j*4][0] */, int k, bool live, const double v[4]) {
+struct RowStore { unsigned o0, o1; };   // plane-relative offsets (doubles) of the lane's two stores
+__device__ __forceinline__ RowStore row_store_setup(Scr S, int slot, int j, int k) {
+  const int p0 = j * 4 + ((k & 1) ? 2 : 0);
+  const unsigned base = (unsigned)(k / CL) * S.cse + (unsigned)slot * 16;
+  return RowStore{(base + ppos(p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(p0 + 1)) * CL + ((k & (CL - 1)) & ~1)};
+}
+__device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[q][0] */, const RowStore& R, int k, bool live, const double v[4]) {
   const bool odd = k & 1;
   const double r0 = swz_xor4(odd ? v[0] : v[2]), r1 = swz_xor4(odd ? v[1] : v[3]);
   if (live) {
-    double* p = row0 + (size_t)(odd ? 2 : 0) * CL + ((k & (CL - 1)) & ~1);
-    *reinterpret_cast<double2*>(p) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
-    *reinterpret_cast<double2*>(p + CL) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
+    *reinterpret_cast<double2*>(plane + R.o0) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
+    *reinterpret_cast<double2*>(plane + R.o1) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
   }
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
@@ -367,6 +378,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     const SlabId sid = flat_slab(GA.nwork, GA.order);
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
+  const RowStore RS = row_store_setup(GA.S, slot, j, kc);
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
   //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   auto put = [&](const Out& o, int q) {
     // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
     // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
-    store_row_pair(Tout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, o.x);
+    store_row_pair(Tout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.x);
     if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
   RowGather RG;
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
     const SlabId sid = flat_slab(GA.nwork, GA.order);
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
+  const RowStore RS = row_store_setup(GA.S, slot, j, kc);
   LapGeo L;
   {
     RowGeo g;
@@ -557,7 +570,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
       double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
       double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
       laplace_lean_row(D, L, x, l1);
-      store_row_pair(Bout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, l1);   // scratch layout, as T
+      store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, l1);   // scratch layout, as T
       if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = mn; qmax[mm_idx(e, q, k, qsize)] = mx; }
     }
     return;
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   struct Out { double q[4], l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
     if (k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
-    store_row_pair(Bout + t_idx(GA.S, q, slot, j * 4, kc & ~(CL - 1)), kc, k < NLEV, o.l);
+    store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.l);
     if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = o.mn; qmax[mm_idx(e, q, k, qsize)] = o.mx; }
   };
   auto step = [&](int q, const Out* prev, Out& cur) {
@@ -757,7 +770,7 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const 
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
-                       Scr S /* S.tps > 0: src is a scratch field and send_src holds slots, instead of [e][lyr][p] and elements */,
+                       Scr S /* S.tps > 0: src is a scratch field and send_src holds {slot, position}, instead of [e][lyr][p] and {element, point} */,
                        int src_lyr /* layers per element of a plain src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)ncol * nlyr) return;

@@ -29,6 +29,10 @@ module cuda_mod
   public :: cuda_mod_init, euler_step_cuda, qdp_time_avg_cuda, vertical_remap_cuda, copy_qdp_d2h, copy_qdp_h2d
   ! not in the reference's list: the whole tracer step in one device call (the fast path, INTEGRATION.md section 2)
   public :: advec_tracers_remap_rk2_hip
+  ! wall time spent inside the seam (everything between entering a cuda_mod routine and returning to the host code), by entry
+  public :: hip_seam_report
+  real(kind=8), save :: t_seam(5) = 0d0   ! 1 copy_qdp_h2d, 2 copy_qdp_d2h, 3 euler_step_cuda/qdp_time_avg_cuda, 4 whole-step call, 5 vertical_remap_cuda
+  integer(kind=8), save :: t_c0
 
   ! mirror of tse_init_args (include/transport_se_hip.h)
   type, bind(C) :: tse_init_args
@@ -51,6 +55,15 @@ module cuda_mod
   interface
      integer(c_int) function tse_init(ctx, args) bind(C, name='tse_init')
        import; type(c_ptr), intent(out) :: ctx; type(tse_init_args), intent(in) :: args
+     end function
+     integer(c_int) function tse_host_register(ctx, base, bytes) bind(C, name='tse_host_register')
+       import; type(c_ptr), value :: ctx, base; integer(c_size_t), value :: bytes
+     end function
+     integer(c_int) function tse_comm_unique_id(id) bind(C, name='tse_comm_unique_id')
+       import; type(c_ptr), value :: id
+     end function
+     integer(c_int) function tse_comm_init(ctx, id, rank, nranks) bind(C, name='tse_comm_init')
+       import; type(c_ptr), value :: ctx, id; integer(c_int), value :: rank, nranks
      end function
      integer(c_int) function tse_copy_qdp_h2d(ctx, q, stride, qsize_d, nt) bind(C, name='tse_copy_qdp_h2d')
        import; type(c_ptr), value :: ctx, q; integer(c_size_t), value :: stride; integer(c_int), value :: qsize_d, nt
@@ -121,6 +134,23 @@ contains
     call abortmp(where//': '//trim(text))
   end subroutine check
 
+  subroutine tic()
+    call system_clock(t_c0)
+  end subroutine tic
+  subroutine toc(i)
+    integer, intent(in) :: i
+    integer(kind=8) :: c1, rate
+    call system_clock(c1, rate)
+    t_seam(i) = t_seam(i) + dble(c1 - t_c0)/dble(rate)
+  end subroutine toc
+  subroutine hip_seam_report(nsteps)
+    integer, intent(in) :: nsteps
+    write(*,'(a,i6,a)') ' hip seam: wall seconds inside the cuda_mod entries over ', nsteps, ' tracer steps'
+    write(*,'(a,5f10.4)') ' hip seam: copy_qdp_h2d copy_qdp_d2h euler_step+time_avg whole_step vertical_remap =', t_seam
+    write(*,'(a,es14.6)') ' hip seam: tracer-DOF-steps/s of the seam alone = ', &
+         dble(nelemd)*np*np*nlev*qsize*nsteps/max(sum(t_seam), 1d-30)
+  end subroutine hip_seam_report
+
   integer(c_size_t) function stride_of(a, b)
     type(c_ptr), intent(in) :: a, b
     stride_of = transfer(b, 0_c_size_t) - transfer(a, 0_c_size_t)
@@ -133,8 +163,11 @@ contains
     type(derivative_t), intent(in) :: deriv
     type(hvcoord_t),    intent(in) :: hvcoord
     type(tse_init_args) :: a
-    integer :: ie, j, ns, nr, e2
+    integer :: ie, j, ns, nr, e2, ierr
     integer(c_int) :: ncs, ncr
+    character(len=16) :: xmode
+    logical :: use_rccl
+    character(kind=c_char), target, save :: comm_id(128)
     allocate(putm(8,nelemd), getm(8,nelemd), revm(8,nelemd))
     do ie = 1, nelemd
        putm(:,ie) = elem(ie)%desc%putmapP(1:8)
@@ -172,8 +205,25 @@ contains
     a%nsend = ns; a%send_peer = c_loc(speer); a%send_ptrP = c_loc(sptr); a%send_lengthP = c_loc(slen)
     a%nrecv = nr; a%recv_peer = c_loc(rpeer); a%recv_ptrP = c_loc(rptr); a%recv_lengthP = c_loc(rlen)
     a%exchange = c_null_funptr; a%exchange_user = c_null_ptr
-    if (ns + nr > 0) a%exchange = c_funloc(tse_f_exchange)
+    ! bndry_exchangeV: TSE_EXCHANGE=rccl (one rank per GPU) lets the library exchange the halo itself with RCCL send/recv on its
+    ! own stream -- the communicator id travels over MPI once, below; otherwise the MPI body of tse_f_exchange is the callback
+    call get_environment_variable('TSE_EXCHANGE', xmode)
+    use_rccl = (trim(xmode) == 'rccl') .and. hybrid%par%nprocs > 1
+    if (ns + nr > 0 .and. .not. use_rccl) a%exchange = c_funloc(tse_f_exchange)
+    call get_environment_variable('TSE_DEVICE_PER_RANK', xmode)
+    if (trim(xmode) == '1') a%device = hybrid%par%rank        ! single node: MPI rank r drives GPU r
     call check(tse_init(ctx, a), 'cuda_mod_init')
+    ! elem(:) is one contiguous allocation (prim_driver_mod.F90:221): page-lock it once, so that copy_qdp_h2d/d2h and the
+    ! per-step derived fields are single 2-D DMAs straight out of / into the element structures
+    if (nelemd > 1) then
+       call check(tse_host_register(ctx, c_loc(elem(1)), stride_of(c_loc(elem(1)), c_loc(elem(2)))*int(nelemd,c_size_t)), &
+                  'tse_host_register')
+    endif
+    if (use_rccl) then
+       if (hybrid%par%rank == 0) call check(tse_comm_unique_id(c_loc(comm_id)), 'tse_comm_unique_id')
+       call MPI_Bcast(comm_id, 128, MPI_CHARACTER, 0, hybrid%par%comm, ierr)
+       call check(tse_comm_init(ctx, c_loc(comm_id), int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int)), 'tse_comm_init')
+    endif
     if (ns + nr > 0) then
        allocate(x_slen(max(ns,1),2), x_rlen(max(nr,1),2))
        x_slen(1:ns,1) = slen(1:ns); x_rlen(1:nr,1) = rlen(1:nr)
@@ -227,13 +277,17 @@ contains
   subroutine copy_qdp_h2d(elem, nt)
     type(element_t), intent(in), target :: elem(:)
     integer, intent(in) :: nt
+    call tic()
     call check(tse_copy_qdp_h2d(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_h2d')
+    call toc(1)
   end subroutine copy_qdp_h2d
 
   subroutine copy_qdp_d2h(elem, nt)
     type(element_t), intent(in), target :: elem(:)
     integer, intent(in) :: nt
+    call tic()
     call check(tse_copy_qdp_d2h(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_d2h')
+    call toc(2)
   end subroutine copy_qdp_d2h
 
   subroutine euler_step_cuda(np1_qdp, n0_qdp, dt, elem, hvcoord, hybrid, deriv, nets, nete, DSSopt, rhs_multiplier)
@@ -245,17 +299,28 @@ contains
     type(derivative_t),   intent(in)            :: deriv
     integer,              intent(in)            :: nets, nete, DSSopt, rhs_multiplier
     integer(c_size_t) :: s
+    type(c_ptr) :: pdiv, peta, pomg
+    call tic()
     if (nets /= 1 .or. nete /= nelemd) call abortmp('euler_step_cuda(hip): needs NThreads=1 (nets:nete = 1:nelemd)')
     s = estride(elem)   ! every field lives in the same fixed-size element_t, so one stride serves all
-    ! what euler_step_cuda stages from elem%derived on every call (cuda_mod.F90:535-547, 564-586)
-    call check(tse_set_derived(ctx, c_loc(elem(1)%derived%vn0), s, c_loc(elem(1)%derived%dp), s, &
-                               c_loc(elem(1)%derived%eta_dot_dpdn), s, c_loc(elem(1)%derived%omega_p), s), 'tse_set_derived')
-    call check(tse_set_divdp(ctx, c_loc(elem(1)%derived%divdp), s, c_loc(elem(1)%derived%divdp_proj), s), 'tse_set_divdp')
+    ! The CUDA seam stages elem%derived on every call (cuda_mod.F90:535-547, 564-586).  Nothing on the host changes vn0, dp,
+    ! divdp, eta_dot_dpdn or omega_p between the three euler_step calls of a tracer step (prim_advection_mod.F90:614-637), and
+    ! the DSS'd divdp_proj / eta_dot_dpdn of the earlier stages are already on the device, so the inputs are uploaded once per
+    ! tracer step (with the first stage, rhs_multiplier = 0) and only the variable this stage DSSes is copied back.
+    if (rhs_multiplier == 0) then
+       call check(tse_set_derived(ctx, c_loc(elem(1)%derived%vn0), s, c_loc(elem(1)%derived%dp), s, &
+                                  c_loc(elem(1)%derived%eta_dot_dpdn), s, c_loc(elem(1)%derived%omega_p), s), 'tse_set_derived')
+       call check(tse_set_divdp(ctx, c_loc(elem(1)%derived%divdp), s, c_loc(elem(1)%derived%divdp_proj), s), 'tse_set_divdp')
+    endif
     call check(tse_euler_step(ctx, int(np1_qdp,c_int), int(n0_qdp,c_int), dt, int(DSSopt,c_int), int(rhs_multiplier,c_int)), &
                'euler_step_cuda')
-    call check(tse_get_derived(ctx, c_loc(elem(1)%derived%divdp_proj), s, c_loc(elem(1)%derived%eta_dot_dpdn), s, &
-                               c_loc(elem(1)%derived%omega_p), s, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, &
+    pdiv = c_null_ptr; peta = c_null_ptr; pomg = c_null_ptr
+    if (DSSopt == 3) pdiv = c_loc(elem(1)%derived%divdp_proj)   ! DSSdiv_vdp_ave (prim_advection_mod.F90:454-456)
+    if (DSSopt == 1) peta = c_loc(elem(1)%derived%eta_dot_dpdn)
+    if (DSSopt == 2) pomg = c_loc(elem(1)%derived%omega_p)
+    call check(tse_get_derived(ctx, pdiv, s, peta, s, pomg, s, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, &
                                c_null_ptr, 0_c_size_t), 'tse_get_derived')
+    call toc(3)
   end subroutine euler_step_cuda
 
   ! The body of Prim_Advec_Tracers_remap_rk2 (prim_advection_mod.F90:600-636: divdp = div(vn0), three euler_steps, qdp_time_avg)
@@ -270,6 +335,7 @@ contains
     real(kind=real_kind), intent(in)            :: dt
     integer,              intent(in)            :: n0_qdp, np1_qdp
     integer(c_size_t) :: s
+    call tic()
     s = estride(elem)
     call check(tse_set_derived(ctx, c_loc(elem(1)%derived%vn0), s, c_loc(elem(1)%derived%dp), s, &
                                c_loc(elem(1)%derived%eta_dot_dpdn), s, c_loc(elem(1)%derived%omega_p), s), 'tse_set_derived')
@@ -278,13 +344,16 @@ contains
     call check(tse_get_derived(ctx, c_loc(elem(1)%derived%divdp_proj), s, c_loc(elem(1)%derived%eta_dot_dpdn), s, &
                                c_loc(elem(1)%derived%omega_p), s, c_loc(elem(1)%derived%divdp), s, c_null_ptr, 0_c_size_t, &
                                c_null_ptr, 0_c_size_t), 'tse_get_derived')
+    call toc(4)
   end subroutine advec_tracers_remap_rk2_hip
 
   subroutine qdp_time_avg_cuda(elem, rkstage, n0_qdp, np1_qdp, limiter_option, nu_p, nets, nete)
     type(element_t),      intent(inout) :: elem(:)
     real(kind=real_kind), intent(in)    :: nu_p
     integer,              intent(in)    :: rkstage, n0_qdp, np1_qdp, nets, nete, limiter_option
+    call tic()
     call check(tse_qdp_time_avg(ctx, int(rkstage,c_int), int(n0_qdp,c_int), int(np1_qdp,c_int)), 'qdp_time_avg_cuda')
+    call toc(3)
   end subroutine qdp_time_avg_cuda
 
   ! call site: vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,nets,nete)   (prim_advection_mod.F90:1280)
@@ -296,6 +365,7 @@ contains
     integer(c_size_t) :: s
     integer :: ie
     real(kind=real_kind), allocatable, target :: dp3d(:,:,:,:), psv(:,:,:)
+    call tic()
     s = estride(elem)
     call check(tse_set_derived(ctx, c_null_ptr, 0_c_size_t, c_loc(elem(1)%derived%dp), s, c_null_ptr, 0_c_size_t, &
                                c_null_ptr, 0_c_size_t), 'tse_set_derived')
@@ -310,6 +380,7 @@ contains
        elem(ie)%state%dp3d(:,:,:,np1) = dp3d(:,:,:,ie)
        elem(ie)%state%ps_v(:,:,np1)   = psv(:,:,ie)
     enddo
+    call toc(5)
   end subroutine vertical_remap_cuda
 
 end module cuda_mod
