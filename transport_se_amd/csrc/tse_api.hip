@@ -49,7 +49,7 @@ struct tse_ctx {
   int2 *dss_tab = nullptr, *send_src = nullptr;
   int *nbr = nullptr, *order = nullptr;
   // state
-  double *qdp = nullptr, *T = nullptr, *B = nullptr;
+  double *qdp = nullptr, *T = nullptr, *B = nullptr, *C = nullptr;   // C: third scratch field (stage-3 output of the whole-step path)
   double *vn0 = nullptr, *dp = nullptr, *divdp = nullptr, *divdp_proj = nullptr, *eta = nullptr, *omega_p = nullptr;
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
@@ -409,9 +409,9 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   // contributions, + the received halo columns, which DSS-on-read reads from there); see tse_kernels.h
   c->tps = ((size_t)NCHUNK * c->cse * CL + 15) / 16 * 16;
   if (c->tps < (size_t)n * 16 * NLEV) return fail("tse_init: scratch plane smaller than a tracer plane");
-  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps))
-    return fail("tse_init: out of device memory (%zu B per tracer field)", trc * 8);
-  HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8));
+  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps) || dalloc(&c->C, c->qsize * c->tps))
+    return fail("tse_init: out of device memory (%zu B per tracer field, 5 fields)", trc * 8);
+  HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->C, 0, c->qsize * c->tps * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
       dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)NLEV * c->qsize) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
@@ -468,7 +468,7 @@ void tse_finalize(tse_ctx* c) {
   if (c->pin_hi) (void)hipHostUnregister((void*)c->pin_lo);
   for (int i = 0; i < 2; i++) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
-                  c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
+                  c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
                   c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->pslots, c->plist_bnd,
                   c->plist_int, c->pring, c->plds, c->send_src_s};
@@ -957,28 +957,28 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   if (dss_level_var(c, &c->eta, NLEVP)) return 1;
 
   // ---- stage 3 (rhs_multiplier 2, DSS extra = omega_p)
-  // 3a: B (+) edges -> Qdp(np1) after stage 2, its first Laplacian (pre-DSS) in T, element min/max; the bounds and the
-  //     Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
+  // 3a: B (+) edges -> first Laplacian (pre-DSS) of the stage-2 tracers in T, element min/max (the DSS'd tracers themselves are
+  //     not stored: 3b assembles them again from B); the bounds and the Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
   if (split_stage(c, "lap",
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
-                             c->divdp_proj, c->qmin, c->qmax, Qnp1, gargs(w));
+                             c->divdp_proj, c->qmin, c->qmax, (double*)nullptr, gargs(w));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
                               unpack_halo(c, cs, c->T, nq); })) return 1;
   if (nbr_minmax_kernel(c)) return 1;
-  // 3b: Qdp(np1), T (+) edges -> B (2nd Laplacian + biharmonic scaling + advance + limiter)
+  // 3b: B (+) edges, T (+) edges -> C (2nd Laplacian + biharmonic scaling + advance + limiter)
   if (split_stage(c, "advance2",
         [&](Work w) -> int {
           if (!w.npwork) return 0;
-          hipLaunchKernelGGL((k_advance<2, 2>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qnp1,
-                             (const double*)c->T, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
+          hipLaunchKernelGGL((k_advance<2, 3>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->B,
+                             (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
-                              unpack_halo(c, cs, c->B, nq + NLEV); })) return 1;
+        [&]() -> int { return pack_tracers(c, cs, c->C, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
+                              unpack_halo(c, cs, c->C, nq + NLEV); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
-  if (dss_tracer_pass(c, c->B, Qnp1, Qn0)) return 1;
+  if (dss_tracer_pass(c, c->C, Qnp1, Qn0)) return 1;
   return dss_level_var(c, &c->omega_p, NLEV);
 }
 
@@ -1159,7 +1159,7 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   struct Ent { const char* n; void* p; size_t b; };
   const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8, scr = (size_t)c->qsize * c->tps * 8;
   const size_t m2 = (size_t)2 * c->qsize * NLEV * 8;
-  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr}, {"B", c->B, scr}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
+  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr}, {"B", c->B, scr}, {"C", c->C, scr}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
                 {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
                 {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},
                 {"qmax", c->qmax, mm}, {"sendbuf", c->sendbuf, (size_t)c->ncol_send * c->nlyr_halo * 8},

@@ -356,7 +356,8 @@ __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 // GIN: DSS on read (whole-step path; block = patch x chunk, see above).  1: the tracer input is rspheremp*DSS of the previous
-// stage's pre-DSS scratch (passed in Qn0, scratch layout); 2: the Laplacian input `lap` is (RHS == 2 only).
+// stage's pre-DSS scratch (passed in Qn0, scratch layout); 2: the Laplacian input `lap` is (RHS == 2 only); 3: both -- stage 3
+// then never needs the DSS'd stage-2 tracers in memory (k_lap1 does not store them).
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
-  __shared__ PatchLds lds_;   // (unused and removed by the compiler when GIN == 0)
+  __shared__ PatchLds lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
   PatchId pid{};
@@ -427,29 +428,32 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
   RowGather RG;
-  GatherRaw graw;                                        // raw own / ring loads of the gathered input (DSS on read)
+  GatherRaw graw, graw2;                                 // raw own / ring loads of the gathered input(s) (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
-  const double* gsrc = GIN == 1 ? Qn0 : lap;
+  const double* gsrc = GIN == 2 ? lap : Qn0;             // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
   auto fetch = [&](int q) {   // loads only
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = mm_idx(e, q, kc, qsize);
     if (GIN) gather_issue(RG, GA, gsrc, q, graw);
-    if (GIN != 1) load4(Qn0 + so, qnx);
-    if (RHS == 2 && GIN != 2) load4(lap + so, lsx);
+    if (GIN == 3) gather_issue(RG, GA, lap, q, graw2);
+    if (GIN == 0 || GIN == 2) load4(Qn0 + so, qnx);
+    if (RHS == 2 && GIN < 2) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
   };
-  if (GIN) gather_setup(RG, lds_, GA, pid);
+  if (GIN) gather_setup(RG, lds_[0], GA, pid);
+  if (GIN == 3 && threadIdx.x < 2 * CL) lds_[GIN == 3 ? 1 : 0].v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;
   fetch(0);
   // Memory schedule with DSS on read: wait for this tracer's own/ring loads -> publish them in LDS -> issue the previous
   // tracer's stores and the next tracer's loads -> workgroup barrier -> neighbour values from LDS -> compute.
   auto step = [&](int q, const Out* prev, Out& cur) {
-    double qn[4], ls[4] = {0, 0, 0, 0}, own[4], minp = minx, maxp = maxx;
-    if (GIN) gather_publish(RG, lds_, q & 1, kc, graw, own);
-    if (GIN != 1) {
+    double qn[4], ls[4] = {0, 0, 0, 0}, own[4], own2[4], minp = minx, maxp = maxx;
+    if (GIN) gather_publish(RG, lds_[0], q & 1, kc, graw, own);
+    if (GIN == 3) gather_publish(RG, lds_[GIN == 3 ? 1 : 0], q & 1, kc, graw2, own2);
+    if (GIN == 0 || GIN == 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
       asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
     }
-    if (RHS >= 2 && GIN != 2) {
+    if (RHS >= 2 && GIN < 2) {
 #pragma unroll
       for (int i = 0; i < 4; i++) ls[i] = lsx[i];
       asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]) : : "memory");
@@ -461,7 +465,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     __builtin_amdgcn_sched_barrier(0);
     if (GIN) {
       lds_barrier();
-      gather_sum(RG, lds_, q & 1, j, own, GIN == 1 ? qn : ls);
+      gather_sum(RG, lds_[0], q & 1, j, own, GIN == 2 ? ls : qn);
+      if (GIN == 3) gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
     }
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
@@ -526,7 +531,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
 // GIN == 1 (whole-step path; block = patch x chunk): Qn0 is the stage-2 pre-DSS scratch; the DSS'd Qdp is assembled on read
-// and also stored to Qout (stage 3 reads it again in k_advance).
+// and, if Qout is given, also stored there (the default k_advance<2,3> of stage 3 assembles it again itself instead).
 template <int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   // the whole step and nothing waits for them.
   struct Out { double q[4], l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
-    if (k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
+    if (Qout && k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
     store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.l);
     if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = o.mn; qmax[mm_idx(e, q, k, qsize)] = o.mx; }
   };
