@@ -27,12 +27,14 @@ ALG_BYTES_PER_DOF_STEP = 400.0 / 3.0   # 16 2/3 mandatory fp64 fiel
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per DOF of ONE launch of each kernel (DESIGN.md "kernels"): tracer fields read + written, 8 B each.
 # Default path (DSS on read): advance0 = k_advance<0> (Qdp -> T), advance1 = k_advance<1,1> (T -> B), lap = k_lap1<1>
-# (B -> Qdp(np1), Laplacian), advance2 = k_advance<2,2> (Qdp(np1), Laplacian -> B), dss = k_dss_t2<1> (B, Qdp(n0) -> Qdp(np1)).
-KERNEL_BYTES_PER_DOF = {"advance0": 16.0, "advance1": 16.0, "lap": 24.0, "advance2": 24.0, "dss": 24.0, "remap": 16.0}
+# (B -> Laplacian in T), advance2 = k_advance<2,3> (B, T -> C), dss = k_dss_patch<1> (C, Qdp(n0) -> Qdp(np1)): 12 field passes per
+# tracer step + 2/3 for the remap = 101 B per DOF-step.
+KERNEL_BYTES_PER_DOF = {"advance0": 16.0, "advance1": 16.0, "lap": 16.0, "advance2": 24.0, "dss": 24.0, "remap": 16.0}
+KERNEL_NAMES = {"advance0": "k_advance<0,0>", "advance1": "k_advance<1,1>", "advance2": "k_advance<2,3>", "lap": "k_lap1<1>",
+                "dss": "k_dss_patch<1>", "remap": "k_remap<1>"}
 if os.environ.get("TSE_DSS_ON_READ", "1") == "0":   # one DSS pass per stage: 4 dss launches (3 x 16 + 24), lap = k_lap1<0>
-    KERNEL_BYTES_PER_DOF.update({"lap": 16.0, "dss": (16.0 + 16.0 + 16.0 + 24.0) / 4.0})
-KERNEL_NAMES = {"advance0": "k_advance<0,0>", "advance1": "k_advance<1,1>", "advance2": "k_advance<2,2>", "lap": "k_lap1<1>",
-                "dss": "k_dss_t2<1>", "remap": "k_remap<1>"}
+    KERNEL_BYTES_PER_DOF.update({"dss": (16.0 + 16.0 + 16.0 + 24.0) / 4.0})
+    KERNEL_NAMES.update({"advance1": "k_advance<1,0>", "advance2": "k_advance<2,0>", "lap": "k_lap1<0>", "dss": "k_dss_patch<0|1>"})
 
 
 def kernel_source_hash():

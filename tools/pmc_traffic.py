@@ -45,7 +45,11 @@ for k, c in sorted(acc.items()):
         e["l2_hit_rate"] = h / (h + m) if h + m else None
         e["tcc_miss_x128B_per_launch"] = m / len(c["TCC_MISS_sum"]) * 128
     kern[k] = e
-json.dump({"config": {"ne": ne, "nlev": 72, "qsize": qsize, "n_gpus": ngpu},
+import hashlib
+_h = hashlib.sha256()
+for _f in ("tse_api.hip", "tse_kernels.h", "tse_device.h"):   # the same hash bench.py prints: ties the counters to a build
+    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transport_se_amd", "csrc", _f), "rb").read())
+json.dump({"config": {"ne": ne, "nlev": 72, "qsize": qsize, "n_gpus": ngpu}, "kernel_source_hash": _h.hexdigest()[:16],
            "command": "tools/pmc_passes.sh: rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 3 --warmup 0 "
                       "--no-cpu-baseline, C in {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} (separate passes)",
            "corrections": __doc__.split("Corrections", 1)[1].strip(), "kernels": kern}, open(out, "w"), indent=1)
