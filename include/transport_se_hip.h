@@ -162,6 +162,13 @@ int tse_dcmip_step_inputs(tse_ctx *ctx, int nstep, double tstep);
 /* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out */
 int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
 
+/* ---- diagnostics ---- */
+/* out[ie][q] = sum_k sum_ij spheremp(i,j,ie) * Qdp(i,j,k,q,nt): the element's share of global_integral of the tracer mass
+ * (global_norms_mod.F90:39-86, prim_state_mod.F90:352-385), summed in a fixed order inside the element so that it is
+ * bit-identical however the elements are distributed; add the elements up with an exact / fixed-order sum for the
+ * reference's task-count-independent result (repro_sum's purpose, global_norms_mod.F90:66-68). */
+int tse_element_mass(tse_ctx *ctx, int nt, double *out);
+
 /* ---- introspection for tests and the benchmark harness ---- */
 /* device pointers of internal fields: "qdp" [2][nelemd][qsize][nlev][16], "vn0", "dp", "divdp", "divdp_proj",
  * "eta_dot_dpdn", "omega_p", "dp3d", "ps_v", "qmin", "qmax", "sendbuf", "recvbuf" */

@@ -49,6 +49,30 @@ def test_ne30_q35_three_steps_and_remap_vs_oracle():
     hip.close(); o.close()
 
 
+def test_qsize_200_three_steps_and_remap_vs_oracle():
+    """BASELINE configs[4] is the qsize=200 tracer stress at ne120 on 8 GPUs; its tracer count (beyond the reference's compile-time
+    QSIZE_D=35) is exercised here on a mesh the oracle handles in seconds: ne8, 200 tracers, one rsplit cycle, every tracer"""
+    import pyoracle as po
+    from gpu_common import elem_from_oracle, make_hip
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    o = po.Oracle(8, 200, nu_q=6e16, threads=threads)
+    elem = elem_from_oracle(o)
+    del elem["Qdp"]
+    hip = make_hip(o, elem, device=0)
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm)
+    hip.dcmip_set_initial()
+    o.dcmip_init(1)
+    assert hip.prim_run_subcycle(400.0, 1, 0) == 3
+    done, _ = o.prim_run(1, 400.0, 1)
+    assert done == 3
+    got = hip.fetch("qdp", (2, o.nelem, 200, 72, 4, 4))[1]
+    ref = o.qdp[1]
+    scale = np.abs(ref).reshape(o.nelem, 200, -1).max(2).max(0)
+    err = np.abs(got - ref).reshape(o.nelem, 200, -1).max(2).max(0) / scale
+    assert err.max() <= 4 * TOL_STEP, err.max()
+    hip.close(); o.close()
+
+
 def _dev_tensor(torch, ptr, shape, dtype="<f8"):
     iface = {"shape": tuple(int(x) for x in shape), "typestr": dtype, "data": (int(ptr), False), "version": 2}
     return torch.as_tensor(type("DevArr", (), {"__cuda_array_interface__": iface})(), device="cuda:0")

@@ -58,17 +58,88 @@ def test_product_diagnostics_agree_with_the_checker():
     assert dg.dcmip_norms(2, g["lat"], g["lon"], q0, q1, zm) == norms.dcmip_norms(2, g["lat"], g["lon"], q0, q1, zm)
 
 
-@pytest.mark.gpu
-def test_prim_main_runs_a_reference_style_namelist(tmp_path):
-    res = subprocess.run([sys.executable, "-m", "transport_se_amd.prim_main"], input=NL.encode(), cwd=str(tmp_path),
-                         env=dict(os.environ, PYTHONPATH=ROOT), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+def _gloo_sum_worker(rank, world, port, partials, gid_parts, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GLOO_SOCKET_IFNAME="lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = gid_parts[rank]
+    out = dg.global_sum(partials[g], g, partials.shape[0], dist, rank, world)
+    full = dg.gather_by_gid(partials[g], g, partials.shape[0], dist, rank, world)
+    if rank == 0:
+        q.put((out, full))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_sum_is_independent_of_the_partition(world):
+    """the multi-rank mass/`qv=` sums: per-element partials gathered over gloo and added exactly -> the same bits for any
+    distribution of the elements (what repro_sum gives the reference, global_norms_mod.F90:66-68)"""
+    import torch.multiprocessing as mp
+    rng = np.random.default_rng(11)
+    n = 96
+    partials = rng.standard_normal((n, 5)) * 10.0 ** rng.integers(-8, 8, size=(n, 5))     # wildly different magnitudes
+    ref = dg.global_sum(partials, np.arange(n), n)
+    perm = rng.permutation(n)
+    gid_parts = np.array_split(perm, world)                       # an arbitrary (non-contiguous) ownership
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 500 + world
+    procs = [ctx.Process(target=_gloo_sum_worker, args=(r, world, port, partials, gid_parts, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+    assert np.array_equal(out, ref) and np.array_equal(full, partials)
+    assert not np.array_equal(ref, partials.sum(0)) or True       # (a plain float sum may or may not agree; fsum is the contract)
+
+
+NL12 = NL.replace('test_case = "dcmip1-1"', 'test_case = "dcmip1-2"').replace("nmax = 6             ! six tracer steps", "ndays = 1").replace("statefreq = 3", "statefreq = 108")
+PREQX = os.path.join(ROOT, "bin", "preqx")
+
+
+def _run_preqx(args, nl, cwd, env_extra=None, timeout=600):
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    res = subprocess.run([PREQX] + args, input=nl.encode(), cwd=str(cwd), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
     out = res.stdout.decode()
-    assert res.returncode == 0, out[-2000:]
-    assert "DCMIP 1-1: L1=" in out and "qv(1)=" in out
+    assert res.returncode == 0, out[-3000:]
+    return out
+
+
+@pytest.mark.gpu
+def test_preqx_dcmip12_norm_line_equals_the_reference_run(tmp_path):
+    """`bin/preqx < namelist` (the reference scripts' $EXE < dcmip1-2.nl, test/run_ne8_tests.sh) for the 1-day DCMIP 1-2 case:
+    the printed norm line against the same run of the reference built here (tests/golden/ref_ne8_norms.json) and README:96"""
+    import json
+    out = _run_preqx([], NL12, tmp_path)
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_ne8_norms.json")))["dcmip1-2"]
+    line = [l for l in out.splitlines() if l.startswith("DCMIP 1-2:")][0]
+    import re
+    got = {k: float(v) for k, v in re.findall(r"(\w+)=\s*([-+0-9.eE]+)", line.split(":", 1)[1])}
+    for k in ("L1", "L2", "Linf", "q_max"):
+        assert abs(got[k] - ref[k]) <= 1e-6 * abs(ref[k]) + 5e-7, (k, got[k], ref[k])        # 6 printed digits
+    assert (got["L1"], got["L2"], got["Linf"], got["q_max"]) == (0.307665, 0.622099, 0.839133, 0.813105)   # README:96
     stats = open(os.path.join(str(tmp_path), "HommeTime_stats")).read()
     for name in ("prim_run", "prim_advance_exp", "prim_advec_tracers", "vertical_remap"):   # run_ne120_perf.sh:140-144
         assert name in stats
-    # mass conserved (the "Q,Q diss" check)
-    for line in out.splitlines():
-        if line.startswith("Q") and "relative change" in line:
-            assert abs(float(line.split("relative change")[1].strip(" )"))) < 1e-12
+    assert "qv(2)=" in out
+    for l in out.splitlines():                                    # mass conserved (the "Q,Q diss" check)
+        if l.startswith("Q") and "relative change" in l:
+            assert abs(float(l.split("relative change")[1].strip(" )"))) < 1e-11
+
+
+@pytest.mark.gpu
+def test_preqx_prints_the_same_digits_on_1_2_and_4_ranks(tmp_path):
+    """norm line, `qv=` lines and tracer-mass lines are string-identical however the sphere is cut (the ranks share the one GPU
+    here: TSE_EXCHANGE=staged; on a multi-GPU node the same command runs one rank per GPU over RCCL)"""
+    def lines(out):
+        return [l for l in out.splitlines() if l.startswith(("DCMIP", "Q")) and "wall" not in l or "qv(" in l]
+    nl = NL.replace("nmax = 6             ! six tracer steps", "nmax = 12")
+    one = lines(_run_preqx([], nl, tmp_path))
+    assert len(one) >= 1 + 4 + 4
+    for n in (2, 4):
+        many = lines(_run_preqx(["--gpus", str(n)], nl, tmp_path, {"TSE_EXCHANGE": "staged"}))
+        assert many == one, "\n".join(["%d ranks:" % n] + many + ["1 rank:"] + one)
+    stats = open(os.path.join(str(tmp_path), "HommeTime_stats")).read()
+    assert " 4 " in stats.splitlines()[1]                         # processes column of the last (4-rank) run

@@ -49,7 +49,7 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
            "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_info",
-           "tse_boundary_layout", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register"]
+           "tse_boundary_layout", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass"]
 COMM_ID_BYTES = 128
 
 
@@ -96,5 +96,6 @@ def lib():
     L.tse_laplace_sphere_wk.argtypes = [vp, vp, vp]
     L.tse_remap_q_ppm.argtypes = [vp, vp, vp, vp]
     L.tse_host_register.argtypes = [vp, vp, sz]
+    L.tse_element_mass.argtypes = [vp, i, vp]
     _lib = L
     return L

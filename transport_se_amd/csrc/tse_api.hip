@@ -1091,6 +1091,22 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
   return rc;
 }
 
+// per-element tracer mass of time level nt -> host out[nelemd][qsize] (fixed summation order inside an element; the caller adds
+// the elements up reproducibly: transport_se_amd/diagnostics.py)
+int tse_element_mass(tse_ctx* c, int nt, double* out) {
+  if (nt < 1 || nt > 2 || !out) return fail("tse_element_mass: nt=%d", nt);
+  const size_t n = (size_t)c->nelemd * c->qsize;
+  double* d = nullptr;
+  if (dalloc(&d, n)) return 1;
+  hipLaunchKernelGGL(k_elem_mass, dim3((unsigned)n), dim3(128), 0, c->stream, c->qsize, (const double*)(c->qdp + (size_t)(nt - 1) * c->trc()),
+                     (const double*)c->spheremp, d);
+  int rc = 0;
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("tse_element_mass: launch or copy failed");
+  (void)hipFree(d);
+  return rc;
+}
+
 // ---- prescribed fields + device-resident driver ---------------------------------------------------
 int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, const double* hyam, const double* hybm) {
   if (test != 1 && test != 2) return fail("tse_dcmip_init: test_case=%d", test);

@@ -109,6 +109,29 @@ __global__ __launch_bounds__(256) void k_elem_op(int nelemd, Dvv_t D, GeoPtrs G,
   if ((t >> 2) < nelemd) store4(out + (size_t)e * 16 + j * 4, r);
 }
 
+// Per-element tracer mass sum_k sum_p spheremp(p) * Qdp(p,k,q) -- the element's share of global_integral behind the "Q, Q diss"
+// diagnostics (global_norms_mod.F90:39-86, prim_state_mod.F90:352-385) -- in a FIXED order (points 0..15 inside a level, then
+// levels 0..71), so that an element's partial does not depend on which rank or block computed it; the cross-element sum is
+// done by the caller with an exact (order-independent) summation.  block = (element, tracer), thread = level.
+__global__ __launch_bounds__(128) void k_elem_mass(int qsize, const double* __restrict__ Q, const double* __restrict__ spheremp, double* __restrict__ out) {
+  __shared__ double lev[NLEV];
+  const int e = blockIdx.x / qsize, q = blockIdx.x - e * qsize, k = threadIdx.x;
+  if (k < NLEV) {
+    const double* x = Q + (((size_t)e * qsize + q) * NLEV + k) * 16;
+    const double* w = spheremp + (size_t)e * 16;
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; p++) s = s + w[p] * x[p];
+    lev[k] = s;
+  }
+  __syncthreads();
+  if (k == 0) {
+    double s = 0.0;
+    for (int l = 0; l < NLEV; l++) s = s + lev[l];
+    out[blockIdx.x] = s;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
 __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize, double rdt /* rhs_multiplier*dt */,

@@ -6,7 +6,16 @@
 * `tracer_mass`: the conserved integral behind the "Q,Q diss" line (prim_state_mod.F90:352-385 through
   global_integral, global_norms_mod.F90:39-86).
 * `printstate_lines`: the `qv=  min max sum` lines of prim_printstate (prim_state_mod.F90:341-347).
+* `global_sum` / `gather_by_gid`: the multi-rank forms.  The reference makes its global integrals independent of the task
+  count with a fixed-point reproducible sum (repro_sum_mod.F90:216-632; "independent of thread count and task count",
+  global_norms_mod.F90:66-68).  Here every ELEMENT's partial sum is formed in a fixed order (on the device:
+  tse_element_mass), the partials travel to rank 0, and rank 0 adds them with math.fsum -- the correctly rounded exact sum,
+  which does not depend on the order, hence not on how the elements were distributed.  Fields needed whole (the norm
+  calculator works on the unique-column grid) are reassembled on rank 0 in global element order, after which every number
+  is computed exactly as on one rank.
 """
+import math
+
 import numpy as np
 
 G = 9.80616      # physical_constants.F90:23
@@ -66,3 +75,33 @@ def printstate_lines(qdp, dp):
     """(min, max, sum) of Q = Qdp/dp per tracer, as the `qv=` lines print them"""
     q = qdp / dp[:, None]
     return [(float(q[:, t].min()), float(q[:, t].max()), float(q[:, t].sum())) for t in range(q.shape[1])]
+
+
+def gather_by_gid(local, gid, nelem, dist_mod, rank, world):
+    """local[n_local, ...] on every rank -> full[nelem, ...] in global element order on rank 0 (None elsewhere)"""
+    if world == 1:
+        full = np.empty((nelem,) + local.shape[1:], dtype=local.dtype)
+        full[gid] = local
+        return full
+    parts = [None] * world if rank == 0 else None
+    dist_mod.gather_object((np.asarray(gid), np.ascontiguousarray(local)), parts, dst=0)
+    if rank != 0:
+        return None
+    full = np.empty((nelem,) + local.shape[1:], dtype=local.dtype)
+    for g, x in parts:
+        full[g] = x
+    return full
+
+
+def global_sum(partials, gid, nelem, dist_mod=None, rank=0, world=1):
+    """partials[n_local][m] (one row per local element, formed in a fixed order) -> [m] exact global sums on rank 0"""
+    full = gather_by_gid(np.asarray(partials, dtype=np.float64), gid, nelem, dist_mod, rank, world)
+    if full is None:
+        return None
+    return np.array([math.fsum(full[:, j].tolist()) for j in range(full.shape[1])])
+
+
+def element_q_partials(qdp, dp):
+    """per element and tracer: (min, max, sum) of Q = Qdp/dp, the sum over the element's points in a fixed (row) order"""
+    q = (qdp / dp[:, None]).reshape(qdp.shape[0], qdp.shape[1], -1)
+    return q.min(2), q.max(2), q.sum(2)

@@ -198,6 +198,12 @@ class HipMod:
         self._chk(self.L.tse_remap_q_ppm(self.h, _vp(q), _vp(d1), _vp(d2)))
         return q
 
+    def element_mass(self, nt):
+        """[nelemd][qsize] per-element tracer mass of time level nt (fixed summation order; see diagnostics.global_sum)"""
+        out = np.empty((self.nelemd, self.qsize))
+        self._chk(self.L.tse_element_mass(self.h, int(nt), _vp(out)))
+        return out
+
     def get_qminmax(self):
         qmin = np.empty((self.nelemd, self.qsize, NLEV)); qmax = np.empty_like(qmin)
         self._chk(self.L.tse_get_qminmax(self.h, _vp(qmin), _vp(qmax)))

@@ -1,16 +1,25 @@
-"""prim_main -- namelist-compatible front end.
+"""prim_main -- namelist-compatible front end, one process per GPU.
 
-    python -m transport_se_amd.prim_main < dcmip1-1.nl
+    python -m transport_se_amd.prim_main < dcmip1-1.nl                 # one GPU
+    python -m transport_se_amd.prim_main --gpus 8 < dcmip1-1.nl        # starts 8 ranks itself (one per GPU)
+    bin/preqx < dcmip1-1.nl                                            # the name the reference's run scripts call ($EXE)
 
 Reads the reference's Fortran namelists from stdin the way prim_main/readnl do (src/prim_main.F90:47,
-src/share/namelist_mod.F90:159-351), runs the device-resident prim_run loop and leaves a `HommeTime_stats` file with the
-four timer names the reference's perf scripts grep (test/run_ne120_perf.sh:140-144: prim_run, prim_advance_exp,
-prim_advec_tracers_remap_rk2, vertical_remap).  Only the ~12 ctl_nl/vert_nl keys the tracer path reads are honoured;
-output (analysis_nl), restart and threading keys are accepted and ignored.  At the end it prints the error-norm line the
-reference's NCL script prints.
+src/share/namelist_mod.F90:159-351: rank 0 reads, everybody gets a copy), runs the device-resident prim_run loop and leaves
+a `HommeTime_stats` file with the four timer names the reference's perf scripts grep (test/run_ne120_perf.sh:140-144:
+prim_run, prim_advance_exp, prim_advec_tracers_remap_rk2, vertical_remap; wallmax = maximum over the ranks).  Only the ~12
+ctl_nl/vert_nl keys the tracer path reads are honoured; output (analysis_nl), restart and threading keys are accepted and
+ignored.  At the end it prints the error-norm line the reference's NCL script prints and the tracer-mass lines; both are
+computed reproducibly (diagnostics.py), so the same run prints the same digits on 1, 2, 4 or 8 GPUs.
+Under an MPI-style launcher (mpiexec/srun: PMI_RANK, OMPI_COMM_WORLD_RANK or SLURM_PROCID in the environment) the ranks
+are taken from it; the control plane is torch.distributed/gloo on MASTER_ADDR:MASTER_PORT (default 127.0.0.1:29531).
 """
+import argparse
+import os
 import re
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -85,50 +94,131 @@ def write_hommetime(path, timers, nranks=1):
     """GPTL-like summary (utils/timing/gptl.c prints name, processes, threads, count, walltotal, wallmax, wallmin)"""
     with open(path, "w") as f:
         f.write("name                                     processes  threads      count    walltotal      wallmax      wallmin\n")
-        for name, (count, sec) in timers.items():
-            f.write("%-40s %9d %8d %10d %12.6f %12.6f %12.6f\n" % (name, nranks, 1, count, sec, sec, sec))
+        for name, (count, tot, mx, mn) in timers.items():
+            f.write("%-40s %9d %8d %10d %12.6f %12.6f %12.6f\n" % (name, nranks, 1, count * nranks, tot, mx, mn))
+
+
+def _rank_world():
+    env = os.environ
+    for r, w in (("RANK", "WORLD_SIZE"), ("PMI_RANK", "PMI_SIZE"), ("OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE"), ("SLURM_PROCID", "SLURM_NTASKS")):
+        if r in env and w in env:
+            return int(env[r]), int(env[w]), int(env.get("LOCAL_RANK", env.get("OMPI_COMM_WORLD_LOCAL_RANK", env.get("SLURM_LOCALID", env[r]))))
+    return 0, 1, 0
 
 
 def main(argv=None):
-    from .driver import PrimRun
-    s = settings(parse_namelists(sys.stdin.read()))
-    run = PrimRun(s["ne"], s["qsize"], test_case=s["test"], nu_q=s["nu_q"], tstep=s["tstep"], rsplit=s["rsplit"])
-    hip = run.hip
+    ap = argparse.ArgumentParser(prog="prim_main")
+    ap.add_argument("--gpus", type=int, default=0, help="start this many ranks (one per GPU) and feed them the namelist from stdin")
+    ap.add_argument("--namelist", default=None, help="read the namelists from this file instead of stdin")
+    a = ap.parse_args(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        text = open(a.namelist).read() if a.namelist else sys.stdin.read()
+        with tempfile.NamedTemporaryFile("w", suffix=".nl", delete=False) as f:
+            f.write(text)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        rc = subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), "-m", "transport_se_amd.prim_main", "--namelist", f.name])
+        os.unlink(f.name)
+        return rc
+    rank, world, local = _rank_world()
+    dist = torch = None
+    exchange = os.environ.get("TSE_EXCHANGE", "rccl")
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        ndev = torch.cuda.device_count()
+        if exchange != "staged" and ndev < world:
+            raise SystemExit("prim_main: %d ranks but %d GPU(s) visible (TSE_EXCHANGE=staged rehearses several ranks on one GPU)" % (world, ndev))
+        local = local % max(ndev, 1)
+        if exchange == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank 0 reads the namelists (stdin or file), everybody gets the text (namelist_mod.F90:318-319 + the MPI_Bcasts after it)
+    box = [None]
+    if rank == 0:
+        box[0] = open(a.namelist).read() if a.namelist else sys.stdin.read()
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    s = settings(parse_namelists(box[0]))
+
     from . import cube_mesh as cm
-    geo = cm.geometry(s["ne"])
-    q0 = run.fetch_qdp(1).copy()
-    dp0 = dg.hybrid_dp(run.hv.hyai, run.hv.hybi, np.full((run.nelem, 4, 4), dg.P0))
+    from .driver import PrimRun
+    run = PrimRun(s["ne"], s["qsize"], test_case=s["test"], nu_q=s["nu_q"], tstep=s["tstep"], rsplit=s["rsplit"], rank=rank, world=world,
+                  device=local, dist_mod=dist, torch_mod=torch, exchange=exchange)
+    hip, gid, nelem = run.hip, run.mine, run.nelem
+    say = print if rank == 0 else (lambda *x, **k: None)
+
+    def gsum(partials):
+        return dg.global_sum(partials, gid, nelem, dist, rank, world)
+
+    def gather(x):
+        return dg.gather_by_gid(x, gid, nelem, dist, rank, world)
+
+    tr = 0 if s["test"] == 1 else 1
+    q0 = gather(run.fetch_qdp(1)[:, tr].copy())              # the norm script's tracer only (Q for 1-1, Q2 for 1-2)
+    m0 = gsum(hip.element_mass(1))
     nsteps = (s["nmax"] // s["rsplit"]) * s["rsplit"]
-    print(" nmax = %d tracer steps, tstep = %g, ne = %d, qsize = %d, nu_q = %g" % (nsteps, s["tstep"], s["ne"], s["qsize"], s["nu_q"]))
+    say(" nmax = %d tracer steps, tstep = %g, ne = %d, qsize = %d, nu_q = %g, %d rank(s), exchange = %s"
+        % (nsteps, s["tstep"], s["ne"], s["qsize"], s["nu_q"], world, run.exchange_kind))
     hip.timing(True)
+    hip.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     np1 = 2
-    for n in range(nsteps):
-        np1 = run.step()
-        if (not s["disable_diagnostics"]) and s["statefreq"] > 0 and run.nstep % s["statefreq"] == 0 and run.nstep % s["rsplit"] == 0:
-            ps_v = hip.fetch("ps_v", (run.nelem, 4, 4))
-            for t, (mn, mx, sm) in enumerate(dg.printstate_lines(run.fetch_qdp(np1), dg.hybrid_dp(run.hv.hyai, run.hv.hybi, ps_v))):
-                print("nstep=%d qv(%d)= %23.15E %23.15E %23.15E" % (run.nstep, t + 1, mn, mx, sm))
+    diag = (not s["disable_diagnostics"]) and s["statefreq"] > 0
+    n = 0
+    while n < nsteps:
+        # run up to the next diagnostics point (a multiple of rsplit and of statefreq) without host synchronisation
+        stop = nsteps
+        if diag:
+            f = s["statefreq"] * s["rsplit"] // np.gcd(s["statefreq"], s["rsplit"])
+            stop = min(nsteps, (run.nstep // f + 1) * f)
+        np1 = run.run(stop - n)
+        n = stop
+        if diag and run.nstep % s["statefreq"] == 0 and run.nstep % s["rsplit"] == 0:
+            ps_v = hip.fetch("ps_v", (gid.size, 4, 4))
+            mn, mx, sm = dg.element_q_partials(run.fetch_qdp(np1), dg.hybrid_dp(run.hv.hyai, run.hv.hybi, ps_v))
+            mn, mx, tot = gather(mn), gather(mx), gsum(sm)
+            for t in range(s["qsize"] if rank == 0 else 0):
+                print("nstep=%d qv(%d)= %23.15E %23.15E %23.15E" % (run.nstep, t + 1, mn[:, t].min(), mx[:, t].max(), tot[t]))
     hip.synchronize()
     wall = time.perf_counter() - t0
-    groups = {k: hip.kernel_time(k) for k in ("advance", "dss", "lap", "minmax", "level", "remap", "dcmip")}
-    adv = sum(groups[k][0] for k in ("advance", "dss", "lap", "minmax", "level")) / 1e3
-    write_hommetime("HommeTime_stats", {
-        "prim_run": (nsteps // s["rsplit"], wall),
-        "prim_advance_exp": (nsteps, groups["dcmip"][0] / 1e3),
-        "prim_advec_tracers_remap_rk2": (nsteps, adv),
-        "vertical_remap": (nsteps // s["rsplit"], groups["remap"][0] / 1e3)})
-    q1 = run.fetch_qdp(np1)
-    ps_v = hip.fetch("ps_v", (run.nelem, 4, 4))
-    tr = 0 if s["test"] == 1 else 1
-    nrm = dg.dcmip_norms(s["ne"], run.lat, run.lon, (q0 / dp0[:, None])[:, tr], (q1 / dg.hybrid_dp(run.hv.hyai, run.hv.hybi, ps_v)[:, None])[:, tr],
-                         dg.level_heights(run.hv.hyam, run.hv.hybm))
-    print("DCMIP 1-%d: L1=%8.6f L2=%8.6f Linf=%8.6f q_max=%8.6f q_min=%14.6e" % (s["test"], nrm["L1"], nrm["L2"], nrm["Linf"], nrm["q_max"], nrm["q_min"]))
-    m0, m1 = dg.tracer_mass(geo["spheremp"], q0), dg.tracer_mass(geo["spheremp"], q1)
-    for t in range(s["qsize"]):
-        print("Q%d mass: %22.14E -> %22.14E (relative change %10.3e)" % (t + 1, m0[t], m1[t], (m1[t] - m0[t]) / max(abs(m0[t]), 1e-300)))
-    print("prim_run wall %.3f s: %.4e tracer-DOF-steps/s" % (wall, run.nelem * 16 * 72 * s["qsize"] * nsteps / wall))
+    groups = {k: hip.kernel_time(k)[0] / 1e3 for k in ("advance", "dss", "lap", "minmax", "level", "remap", "dcmip")}
+    mine = np.array([wall, groups["dcmip"], sum(groups[k] for k in ("advance", "dss", "lap", "minmax", "level")), groups["remap"]])
+    if world > 1:
+        ranks_t = [None] * world if rank == 0 else None
+        dist.gather_object(mine, ranks_t, dst=0)
+        stack = np.stack(ranks_t) if rank == 0 else None
+    else:
+        stack = mine[None]
+    if rank == 0:
+        names = ("prim_run", "prim_advance_exp", "prim_advec_tracers_remap_rk2", "vertical_remap")
+        counts = (nsteps // s["rsplit"], nsteps, nsteps, nsteps // s["rsplit"])
+        write_hommetime("HommeTime_stats", {nm: (cnt, float(stack[:, i].sum()), float(stack[:, i].max()), float(stack[:, i].min()))
+                                            for i, (nm, cnt) in enumerate(zip(names, counts))}, world)
+    # error norms on the unique-column grid (dcmip1-*_error_norm_ng.ncl:39-77) and tracer mass ("Q, Q diss")
+    q1 = gather(run.fetch_qdp(np1)[:, tr].copy())
+    ps_v = gather(hip.fetch("ps_v", (gid.size, 4, 4)))
+    m1 = gsum(hip.element_mass(np1))
+    if rank == 0:
+        geo = cm.geometry(s["ne"])
+        dp0 = dg.hybrid_dp(run.hv.hyai, run.hv.hybi, np.full((nelem, 4, 4), dg.P0))
+        nrm = dg.dcmip_norms(s["ne"], geo["lat"], geo["lon"], q0 / dp0, q1 / dg.hybrid_dp(run.hv.hyai, run.hv.hybi, ps_v),
+                             dg.level_heights(run.hv.hyam, run.hv.hybm))
+        print("DCMIP 1-%d: L1=%8.6f L2=%8.6f Linf=%8.6f q_max=%8.6f q_min=%14.6e" % (s["test"], nrm["L1"], nrm["L2"], nrm["Linf"], nrm["q_max"], nrm["q_min"]))
+        for t in range(s["qsize"]):
+            print("Q%d mass: %22.14E -> %22.14E (relative change %10.3e)" % (t + 1, m0[t], m1[t], (m1[t] - m0[t]) / max(abs(m0[t]), 1e-300)))
+        print("prim_run wall %.3f s: %.4e tracer-DOF-steps/s on %d rank(s)" % (float(stack[:, 0].max()), nelem * 16 * 72 * s["qsize"] * nsteps / float(stack[:, 0].max()), world))
     run.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     return 0
 
 
