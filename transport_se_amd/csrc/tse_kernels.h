@@ -173,11 +173,7 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
   const int S8 = (nelemd + 7) >> 3;
   const int slot = (blockIdx.x & 7) * S8 + (blockIdx.x >> 3);
   if (slot >= nelemd) return;
-#ifdef TSE_MM_PLAIN_ORDER
-  const int e = slot;
-#else
   const int e = order[slot];
-#endif
   const int m = qsize * NLEV;
   const double *pmn[8], *pmx[8];
 #pragma unroll
@@ -842,7 +838,7 @@ struct RemapLds {
   double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
   double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
   double rdpo[NLEV + 4][16];       // 1/dpo (the column loop multiplies instead of dividing)
-  double dpn[NLEV][16];            // derived%dp of the next step (only for the fused min/max emission)
+  double dpn[NLEV][16];            // 1 / derived%dp of the next step (only for the fused min/max emission)
   double z2[NLEV][16];
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
@@ -860,8 +856,7 @@ __device__ __forceinline__ double remap_dma_at(const RemapLds& S, int j, int p, 
 }
 __device__ __forceinline__ double remap_ai_at(const RemapLds& S, int j, int p, double aj, double ajp, double dmajp, double dmaj) {
   return aj + S.ppmdx[j][3][p] * (ajp - aj) +
-         S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (S.ppmdx[j][6][p] - S.ppmdx[j][7][p]) * (ajp - aj) -
-                             S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
+         S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (ajp - aj) - S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
 }
 // limited parabola of one cell from its mean a0 and interface values (compute_ppm stage 3, :309-331)
 __device__ __forceinline__ void remap_coefs(double al, double ar, double a0, double& c0, double& c1, double& c2) {
@@ -928,7 +923,7 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
       col[(size_t)(k - 1) * 16] = qnew;
       massn1 = massn2;
       if (mn_out) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-        const double x = qnew / S.dpn[k - 1][p];
+        const double x = qnew * S.dpn[k - 1][p];
         double mn = x, mx = x;
         mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
         mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
@@ -1018,8 +1013,8 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
       const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
       const double d0 = bp[(jdo * 10 + 0) * 16], d1 = bp[(jdo * 10 + 1) * 16], d2 = bp[(jdo * 10 + 2) * 16];
-      const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e5 = bp[(jao * 10 + 5) * 16], e6 = bp[(jao * 10 + 6) * 16],
-                   e7 = bp[(jao * 10 + 7) * 16], e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
+      const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e567 = bp[(jao * 10 + 5) * 16],
+                   e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
       const int kt = bkid[sl * 16];
       const bool o = kt != k;   // kid(k) == k+1
       const double x1 = -0.5, x2 = bz2[sl * 16], dsel = o ? bdpo[(sl + 3) * 16] : bdpo[(sl + 2) * 16], dn = bdpn[sl * 16];
@@ -1027,7 +1022,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
-        const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e5 * (e6 - e7) * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
+        const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e567 * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
         const double mo1 = masso[t] + mk[t];
         const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
         double c0, c1, c2;
@@ -1038,7 +1033,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
         colw[t][(size_t)(k - 1) * 16] = qnew;
         massn1[t] = massn2;
         if (EMIT) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-          const double x = qnew / dn;
+          const double x = qnew * dn;
           double mn = x, mx = x;
           mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
           mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
@@ -1089,7 +1084,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     double d = dp[o] - dt * divdp_proj[o];
     dp3d[o] = d;
     S.dpo[(w >> 4) + 2][w & 15] = d;
-    S.dpn[w >> 4][w & 15] = dp[o];
+    S.dpn[w >> 4][w & 15] = 1.0 / dp[o];   // Q = Qdp * (1/dp), as k_advance forms its local bounds
     if (d < 0) atomicOr(bad, 1);
   }
   __syncthreads();
@@ -1137,9 +1132,10 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     if (jj <= NLEV) {
       S.ppmdx[jj][3][p] = DX(jj) / (DX(jj) + DX(jj + 1));
       S.ppmdx[jj][4][p] = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
-      S.ppmdx[jj][5][p] = (2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][6][p] = (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][7][p] = (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj));
+      // (:255-257) the three factors of the curvature term only ever appear as c5*(c6 - c7), a level-only product that the
+      // reference evaluates first (left to right): stored once instead of three coefficients
+      S.ppmdx[jj][5][p] = ((2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1))) *
+                          ((DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1)) - (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj)));
       S.ppmdx[jj][8][p] = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
       S.ppmdx[jj][9][p] = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
     }
