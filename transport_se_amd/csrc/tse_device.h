@@ -127,6 +127,10 @@ __device__ __forceinline__ void make_lap_geo(LapGeo& L, const RowGeo& g) {
   }
 }
 __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L, const double s[4], double lap[4]) {
+#ifdef TSE_NO_CONTRACTION   // A/B build: see k_advance
+  for (int i = 0; i < 4; i++) lap[i] = (L.A[i] + L.B[i] + L.C[i]) * s[i];
+  return;
+#endif
   // written point-by-point so that only one set of 4 quad broadcasts is live at a time (register pressure)
   double w1[4], w2[4];
 #pragma unroll

@@ -497,6 +497,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 #pragma unroll
     for (int i = 0; i < 4; i++) { gv1[i] = a1[i] * qn[i]; gv2[i] = a2[i] * qn[i]; }
     // d/dx in-register, d/dy across the quad (deriv_xy with the lane's dcol)
+#ifdef TSE_NO_CONTRACTION   // A/B build (tools/ab): the contractions replaced by a copy -- an upper bound on what a faster contraction could buy
+#pragma unroll
+    for (int i = 0; i < 4; i++) { dx[i] = gv1[i]; dy[i] = gv2[i]; }
+#else
 #pragma unroll
     for (int l = 0; l < 4; l++) {
       double sm = 0.0;
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 #pragma unroll
       for (int i = 0; i < 4; i++) dy[i] = ((dcol[0] * r0[i] + dcol[1] * r1[i]) + dcol[2] * r2[i]) + dcol[3] * r3[i];
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
     bool changed = false;
