@@ -329,10 +329,13 @@ __device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L
                f4 = *reinterpret_cast<const double*>(base + R.lr[4]);
   // quad hand-over: lanes 0 and 3 receive what lanes 1 and 2 fetched for them: quad_perm [1,1,2,2]
   const double d2 = dppq<0xA5>(f2), d3 = dppq<0xA5>(f3), d4 = dppq<0xA5>(f4);
-  double t0 = v[0] + f0; t0 = t0 + (edge ? f1 : 0.0); t0 = t0 + (edge ? d2 : 0.0);
-  double t1 = v[1] + (edge ? d3 : 0.0);
-  double t2 = v[2] + (edge ? d4 : 0.0);
-  double t3 = v[3] + (edge ? f2 : f1); t3 = t3 + (edge ? f3 : 0.0); t3 = t3 + (edge ? f4 : 0.0);
+  // "this contribution belongs to my row" as an exact 1.0/0.0 factor folded into FMAs (fma(1,x,t) = t + x rounds like the
+  // addition, fma(0,x,t) = t; every x is a finite field value) instead of a 64-bit select around every add
+  const double em = edge ? 1.0 : 0.0, nm = edge ? 0.0 : 1.0;
+  double t0 = v[0] + f0; t0 = fma(em, f1, t0); t0 = fma(em, d2, t0);
+  const double t1 = fma(em, d3, v[1]);
+  const double t2 = fma(em, d4, v[2]);
+  double t3 = fma(nm, f1, v[3]); t3 = fma(em, f2, t3); t3 = fma(em, f3, t3); t3 = fma(em, f4, t3);
   out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
 }
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
