@@ -17,7 +17,13 @@ pytestmark = pytest.mark.gpu
 NE, QSIZE, NU_Q, DT = 4, 3, 5e17, 900.0
 
 
-def _run(world):
+def _run(world, ne=None):
+    global NE
+    NE = ne or 4
+    return _run_ne(world)
+
+
+def _run_ne(world):
     hv = HvCoord()
     topo = cm.topology(NE); geo = cm.geometry(NE, topo)
     nelem = 6 * NE * NE
@@ -97,6 +103,15 @@ def _run(world):
     for mine, qq, dd in result:
         q[mine] = qq; dv[mine] = dd
     return q, dv
+
+
+def test_bfb_on_an_irregular_partition():
+    """ne5 on 4 ranks: SFC chunks of 37/38 elements that the 4 x 4 patches cannot tile (partial patches, holes, patches cut by the
+    rank boundary), boundary-first split launches with few or no interior patches"""
+    q1, d1 = _run(1, ne=5)
+    qn, dn = _run(4, ne=5)
+    assert np.isfinite(q1).all() and q1.max() > 0
+    assert np.array_equal(qn, q1) and np.array_equal(dn, d1)
 
 
 def test_bfb_across_rank_counts():

@@ -5,6 +5,7 @@ prescribed winds, so results agree with the fp64 reference to round-off accumula
     TOL_STEP = 5e-13 relative to the field maximum per tracer step.
 (north_star asks for 3 significant figures on the DCMIP norms; see test_gpu_dcmip_norms.py.)"""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -131,6 +132,32 @@ def test_dcmip12_vs_reference_golden(gold):
     assert hip.prim_run_subcycle(cfg["tstep"], 1, 0) == 3
     hip.copy_qdp_d2h(elem, 2)
     assert relerr(elem["Qdp"][:, 1], g["qdp_step3"]) < 5 * TOL_STEP
+    hip.close(); o.close()
+
+
+@pytest.mark.parametrize("ne", [3, 5, 7])
+def test_odd_meshes_partial_patches_vs_oracle(ne):
+    """face sizes that the 4 x 4 element patches of the DSS-on-read kernels do not tile (rows of 3, 1 and 3 elements at the
+    face edges, patches with holes, patches reaching across cube seams): one rsplit cycle against the oracle, both
+    implementations of the step"""
+    o = po.Oracle(ne, 3, nu_q=1e15 * (30.0 / ne) ** 3.2)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    dt = 300.0 * 30.0 / ne
+    o.dcmip_init(1)
+    done, _ = o.prim_run(1, dt, 1)
+    assert done == 3
+    for on_read in ("1", "0"):
+        os.environ["TSE_DSS_ON_READ"] = on_read
+        try:
+            hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+            assert hip.prim_run_subcycle(dt, 1, 0) == 3
+        finally:
+            os.environ.pop("TSE_DSS_ON_READ", None)
+        hip.copy_qdp_d2h(elem, 2)
+        assert relerr(elem["Qdp"][:, 1], o.qdp[1]) < 4 * TOL_STEP, (ne, on_read)
+    nb, ni = hip.boundary_layout()
+    assert (nb, ni) == (0, 6 * ne * ne)
     hip.close(); o.close()
 
 
