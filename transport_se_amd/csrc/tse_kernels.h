@@ -444,8 +444,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   // whole step to drain and nothing waits for them (worth its 12 registers where few waves fit: the DSS-on-read kernels).
   struct Out { double x[4], mn, mx; bool ch; };   // ch: the bounds differ from what qmin/qmax already hold
   auto put = [&](const Out& o, int q) {
-    // pre-DSS output in the gather-friendly layout T[q][e][p][k] (level fastest): the neighbours' edge points that the
-    // DSS adds are then contiguous over the 16 levels of a wave (full 128-B lines instead of 8 B out of each)
+    // pre-DSS output in the scratch layout (chunks of 4 levels, slots, points perimeter first): what the next stage's blocks
+    // load as their own points and as their halo ring
     store_row_pair(Tout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.x);
     if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
@@ -648,16 +648,15 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
 // inverse mass matrix (prim_advection_mod.F90:929-960) and, for MODE 1, with qdp_time_avg (:645-662).
 // Each element adds its neighbours' values in the reference's fixed order (all S, E, N, W, then SW, SE, NE, NW),
 // so results do not depend on how elements are distributed over GPUs.
-//   tab[e][16][3] = {source element (>=0 local, -1 none, <=-2 remote column -(v+2)), source point}
-//   remote values come from recvbuf[col][nlyr_halo] (layer = q*NLEV+k, the reference's message layout).
-// Tracer-field DSS: source in the scratch layout src[q][kc][slot][p][kk] written by k_advance/k_lap1, destination in the
-// standard layout dst[e][q][k][p].  Block = (element, QB consecutive tracers), thread = (level k, row j) as in
-// k_advance; every neighbour contribution is one 8-B load per lane that is contiguous over the 16 levels of the wave.
+//   tab[e][16][3] = {source element (>=0 local, -1 none, <=-2 remote column -(v+2)), source point}  (level fields; the tracer
+//   kernels use the patch tables derived from it: tse_api.hip)
+// Tracer-field DSS (k_dss_patch): source in the scratch layout written by k_advance/k_lap1, destination in the standard
+// layout dst[e][q][k][p].
 // MODE 0: dst = rspheremp * DSS(src)                                   (prim_advection_mod.F90:929-960)
 // MODE 1: ... fused with qdp_time_avg: dst = (Qn0 + 2*that)/3         (:645-662)
-// Lane mapping shared by the tracer DSS kernels: work = (tracer chunk, XCD range of elements, flattened (element slot,
-// unit)) with UNITS lanes per element.  288 (or 144) lanes per element do not fill whole waves, so the lanes of a block run
-// across element boundaries: no idle lanes except in a range's last block, and blocks of 4 waves instead of 5.
+// Lane mapping of the level-field DSS (k_dss_lvl): work = (XCD range of elements, flattened (element slot, unit)) with UNITS
+// lanes per element.  144 lanes per element do not fill whole waves, so the lanes of a block run across element boundaries:
+// no idle lanes except in a range's last block, and blocks of 4 waves instead of 5.
 constexpr int DSS_FLAT_THREADS = 256;
 template <int UNITS>
 inline int dss_blocks_per_xcd(int nelemd) { return (((nelemd + 7) >> 3) * UNITS + DSS_FLAT_THREADS - 1) / DSS_FLAT_THREADS; }
@@ -739,7 +738,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_dss_patch(int qsize, const dou
 // DSS of one level field (divdp_proj, eta_dot_dpdn(1:nlev), omega_p): dst = rspheremp * DSS(spheremp * src)
 // (prim_advection_mod.F90:911-919,943-957), out of place (the neighbours read src).  src/dst carry src_lev/dst_lev levels per
 // element (eta_dot_dpdn: nlev+1; the extra level is copied through), so no staging copies are needed and the caller just
-// swaps the two buffers.  Lanes flattened over (element slot, level, row) like k_dss_t; all gathers issued before any use.
+// swaps the two buffers.  Lanes flattened over (element slot, level pair, row); all gathers issued before any use.
 constexpr int LVL_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs (k, k+36) x 4 rows
 __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const int2* __restrict__ tab, const double* __restrict__ rspheremp,
                                                               const double* __restrict__ spheremp, const double* __restrict__ src, int src_lev,
