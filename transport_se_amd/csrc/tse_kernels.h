@@ -163,7 +163,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
 // neighbor_minmax / min-max half of biharmonic_wk_scalar_minmax (viscosity_mod.F90:748-816,389-432):
 // min/max over the element and its <= 8 neighbours.  nbr[e][8]: >= 0 local element, -1 none,
 // <= -2 remote: column -(v+2) of the received halo (layer index = (q*NLEV+k), min set then max set).
-__global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
+__global__ __launch_bounds__(512) void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
                                                     const double* __restrict__ in_min, const double* __restrict__ in_max,
                                                     double* __restrict__ out_min, double* __restrict__ out_max,
                                                     const double* __restrict__ recvbuf, int nlyr_halo, const int* __restrict__ order) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_nbr_minmax(int nelemd, int qsize, const
     pmx[d] = n >= 0 ? in_max + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m : in_max + (size_t)e * m);
   }
   // two consecutive entries per lane: 16-byte loads/stores (m = qsize*72 is even; so are the halo offsets)
-  for (int l = 2 * threadIdx.x; l < m; l += 512) {
+  for (int l = 2 * threadIdx.x; l < m; l += 2 * blockDim.x) {
     double2 mn = *reinterpret_cast<const double2*>(in_min + (size_t)e * m + l), mx = *reinterpret_cast<const double2*>(in_max + (size_t)e * m + l);
     double2 nmn[8], nmx[8];   // all 16 neighbour loads in flight together
 #pragma unroll
