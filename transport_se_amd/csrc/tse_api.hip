@@ -55,6 +55,8 @@ struct tse_ctx {
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
   int* bad = nullptr;
   int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
+  int mm_halo = 0;    // == mm_valid: the neighbour ranks' share of those bounds is already in recvbuf_mm (or on its way: ev_mm)
+  hipEvent_t ev_mm = nullptr;   // completion of that prefetched exchange on the communication stream
   // halo: one slot per neighbour rank (Schedule(1)%SendCycle/RecvCycle), entries per slot for the two exchange kinds
   int ncol_send = 0, ncol_recv = 0, nlyr_halo = 0;
   int nmm_send = 0, nmm_recv = 0;              // entries of the compact min/max exchange
@@ -107,6 +109,9 @@ struct tse_ctx {
 };
 
 const char* tse_last_error(void) { return g_err; }
+
+// the element bounds of Qdp(tl)/dp now sit in qmin2/qmax2 (tl = 0: nothing cached); any halo of older bounds is stale
+static void set_bounds_cache(tse_ctx* c, int tl) { c->mm_valid = tl; c->mm_halo = 0; }
 
 template <class T>
 static int dalloc(T** p, size_t n) {
@@ -436,6 +441,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     HIPCHK(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
     c->sync_events.assign(16, nullptr);
     for (hipEvent_t& e : c->sync_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
   }
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
@@ -476,6 +482,7 @@ void tse_finalize(tse_ctx* c) {
   resolve_timers(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->sync_events) if (e) (void)hipEventDestroy(e);
+  if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -494,7 +501,7 @@ int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   return 0;
 }
 int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
-int tse_invalidate_cache(tse_ctx* c) { c->mm_valid = 0; return 0; }
+int tse_invalidate_cache(tse_ctx* c) { set_bounds_cache(c, 0); return 0; }
 
 // ---- RCCL communicator ----------------------------------------------------------------------------
 int tse_comm_unique_id(void* id_out) {
@@ -589,7 +596,7 @@ static int copy_field(tse_ctx* c, double* dev, size_t cnt_dev, void* host, size_
   return 0;
 }
 int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, int nt) {
-  c->mm_valid = 0;
+  set_bounds_cache(c, 0);
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_h2d: nt=%d qsize_d=%d", nt, qsize_d);
   const size_t per = (size_t)c->qsize * NLEV * 16;   // Qdp(np,np,nlev,qsize_d,2): time level nt starts qsize_d*nlev*16 doubles in
   if (copy_field(c, c->qdp + (size_t)(nt - 1) * c->trc(), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, true)) return 1;
@@ -613,7 +620,7 @@ int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, 
                     const double* omega_p, size_t s3) {
   // vn0(np,np,2,nlev) in Fortran memory is [k][c][p]: the device layout
   if (put_level(c, c->vn0, vn0, s0, 2 * NLEV * 16, 2 * NLEV * 16)) return 1;
-  if (dp) c->mm_valid = 0;   // bounds were formed with the previous dp
+  if (dp) set_bounds_cache(c, 0);   // bounds were formed with the previous dp
   if (put_level(c, c->dp, dp, s1, NLEV * 16, NLEV * 16)) return 1;
   if (put_level(c, c->eta, eta, s2, NLEVP * 16, NLEVP * 16)) return 1;
   if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
@@ -716,12 +723,12 @@ static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_level
   LAUNCH_CHECK();
   return 0;
 }
-static int pack_minmax(tse_ctx* c, hipStream_t st) {
+static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr, const double* qmax = nullptr) {
   const int m = c->qsize * NLEV;
   if (!c->nmm_send) return 0;
   size_t tot = (size_t)c->nmm_send * m;
   hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
-                     c->qmin, c->qmax, c->sendbuf_mm, 2 * m, 0);
+                     qmin ? qmin : (const double*)c->qmin, qmax ? qmax : (const double*)c->qmax, c->sendbuf_mm, 2 * m, 0);
   LAUNCH_CHECK();
   return 0;
 }
@@ -771,11 +778,11 @@ static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
   return 0;
 }
 // tracer DSS pass src (scratch layout, halo columns filled) -> dst (standard layout), optionally fused with qdp_time_avg and the
-// next step's bounds
-static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg) {
-  Scope s(c, "dss");
-  const GatherArgs ga = c->gargs(nullptr, c->nelemd, nullptr, c->npatch);
-  const dim3 grid(patch_blocks(c->npatch)), blk(FLAT_THREADS);
+// next step's bounds; over all patches (npwork < 0) or over the patch list of a split launch
+static int dss_tracer_launch(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, const int* plist, int npwork) {
+  if (!npwork) return 0;
+  const GatherArgs ga = c->gargs(nullptr, c->nelemd, plist, npwork);
+  const dim3 grid(patch_blocks(npwork)), blk(FLAT_THREADS);
   if (Qn0_avg)
     hipLaunchKernelGGL(k_dss_patch<1>, grid, blk, 0, c->stream, c->qsize, src, dst, Qn0_avg, (const double*)c->dp, c->qmin2, c->qmax2, ga);
   else
@@ -783,6 +790,10 @@ static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const dou
                        (double*)nullptr, (double*)nullptr, ga);
   LAUNCH_CHECK();
   return 0;
+}
+static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg) {
+  Scope s(c, "dss");
+  return dss_tracer_launch(c, src, dst, Qn0_avg, nullptr, c->npatch);
 }
 
 // One euler_step of the per-stage API (prim_advection_mod.F90:667-970): every stage ends with a tracer DSS pass, because
@@ -806,7 +817,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
     }
-    c->mm_valid = 0;
+    set_bounds_cache(c, 0);
     if (neighbor_minmax(c)) return 1;
     Scope s(c, "advance0");
     hipLaunchKernelGGL(k_advance<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dt, c->nu_q, Qn0, (const double*)nullptr, c->T, c->vn0,
@@ -849,12 +860,12 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
 }
 
 int tse_euler_step(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs_multiplier) {
-  c->mm_valid = 0;
+  set_bounds_cache(c, 0);
   return euler_step_impl(c, np1_qdp, n0_qdp, dt, DSSopt, rhs_multiplier, false, 0, false);
 }
 
 int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
-  c->mm_valid = 0;
+  set_bounds_cache(c, 0);
   Scope s(c, "avg");
   size_t n = c->trc();
   hipLaunchKernelGGL(k_time_avg, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
@@ -887,22 +898,28 @@ static Work work_of(const tse_ctx* c, int part) {
   return Work{c->ord_int, c->n_int, c->plist_int, c->np_int};
 }
 
+// done_out == nullptr: the compute stream waits for the communication work before it goes on; otherwise the event that marks
+// its completion is handed back and whoever consumes the halo waits for it (the prefetched bounds exchange)
 template <class Launch, class CommWork>
-static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (Work) */, CommWork comm_work /* () on c->comm_stream */) {
+static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (Work) */, CommWork comm_work /* () on c->comm_stream */,
+                       hipEvent_t* done_out = nullptr) {
   Scope s(c, timer);
   if (!c->halo()) return launch(work_of(c, 0));
   if (launch(work_of(c, 1))) return 1;
-  hipEvent_t evB = next_sync_event(c), evC = next_sync_event(c);
+  hipEvent_t evB = next_sync_event(c), evC = done_out ? c->ev_mm : next_sync_event(c);
   HIPCHK(hipEventRecord(evB, c->stream));
   HIPCHK(hipStreamWaitEvent(c->comm_stream, evB, 0));
   if (c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
   if (launch(work_of(c, 2))) return 1;
   if (!c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
-  HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
+  if (done_out) *done_out = evC;
+  else HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
   return 0;
 }
 
-static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp) {
+// prefetch: the caller knows that the next thing to happen to Qdp(np1) is the next tracer step (no remap in between), so the
+// bounds exchange that step would start with is started here, under the interior part of the last kernel
+static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp, bool prefetch) {
   double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
   double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
   const int nq = c->qsize * NLEV;
@@ -911,6 +928,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   auto gargs = [&](const Work& w) { return c->gargs(w.order, w.nwork, w.plist, w.npwork); };
 
   // ---- stage 1 (rhs_multiplier 0, DSS extra = divdp_proj): bounds, neighbour min/max, advance Qdp(n0) -> T
+  const bool halo_ready = c->halo() && c->mm_valid == n0_qdp && c->mm_halo == n0_qdp;   // prefetched by the previous step / remap
   if (c->mm_valid == n0_qdp) {
     // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
     std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
@@ -919,8 +937,12 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     hipLaunchKernelGGL(k_qminmax, dim3(flat_blocks(c->nelemd)), blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
     LAUNCH_CHECK();
   }
-  c->mm_valid = 0;
-  {   // the min/max halo travels under divdp = div(vn0)
+  set_bounds_cache(c, 0);
+  if (halo_ready) {
+    if (tse_compute_divdp(c)) return 1;
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_mm, 0));
+    if (nbr_minmax_kernel(c)) return 1;
+  } else {   // the min/max halo travels under divdp = div(vn0)
     auto mm_comm = [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs); };
     hipEvent_t ev0 = nullptr, evM = nullptr;
     if (c->halo()) {
@@ -979,11 +1001,21 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&]() -> int { return pack_tracers(c, cs, c->C, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
                               unpack_halo(c, cs, c->C, nq + NLEV); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
-  if (dss_tracer_pass(c, c->C, Qnp1, Qn0)) return 1;
+  if (prefetch && c->halo()) {
+    hipEvent_t done = nullptr;
+    if (split_stage(c, "dss",
+          [&](Work w) -> int { return dss_tracer_launch(c, c->C, Qnp1, Qn0, w.plist, w.npwork); },
+          [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done)) return 1;
+    set_bounds_cache(c, np1_qdp);
+    c->mm_halo = np1_qdp;
+  } else {
+    if (dss_tracer_pass(c, c->C, Qnp1, Qn0)) return 1;
+    set_bounds_cache(c, np1_qdp);
+  }
   return dss_level_var(c, &c->omega_p, NLEV);
 }
 
-int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) {
+static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefetch) {
   if (n0_qdp == np1_qdp || n0_qdp < 1 || n0_qdp > 2 || np1_qdp < 1 || np1_qdp > 2)
     return fail("advec_tracers_remap_rk2: time levels n0_qdp=%d np1_qdp=%d", n0_qdp, np1_qdp);
   bool gor = dss_on_read();
@@ -1002,32 +1034,50 @@ int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) 
       LAUNCH_CHECK();
       c->t_zero_dirty = false;
     }
-    if (advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp)) return 1;
+    return advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp, prefetch);   // (sets the bounds cache itself)
   } else {
     if (tse_compute_divdp(c)) return 1;
     if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, true)) return 1;
     if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 1, 1, false, 0, false)) return 1;
     if (euler_step_impl(c, np1_qdp, np1_qdp, dt / 2, 2, 2, true, n0_qdp, false)) return 1;
   }
-  c->mm_valid = np1_qdp;   // the final DSS emitted min/max of Qdp(np1)/dp for the next step
+  set_bounds_cache(c, np1_qdp);   // the final DSS emitted min/max of Qdp(np1)/dp for the next step
   return 0;
 }
 
-static int remap_launch(tse_ctx* c, double dt, int np1_qdp) {
+int tse_advec_tracers_remap_rk2(tse_ctx* c, double dt, int n0_qdp, int np1_qdp) { return advec_step(c, dt, n0_qdp, np1_qdp, false); }
+
+// prefetch: as in advec_dss_on_read -- the next tracer step's bounds exchange starts under the interior elements of the remap
+static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
   if (np1_qdp < 1 || np1_qdp > 2) return fail("vertical_remap: np1_qdp=%d", np1_qdp);
-  Scope s(c, "remap");
   // TSE_REMAP_NT: tracers per thread in the lockstep column loop; TSE_REMAP_GENERIC=1: always take the generic loop (tests)
   const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
   const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
   double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
-  if (nt == 1)
-    hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr);
-  else
-    hipLaunchKernelGGL(k_remap<2>, dim3(c->nelemd), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr);
-  LAUNCH_CHECK();
-  c->mm_valid = np1_qdp;   // k_remap emitted the element min/max of the remapped field
+  auto launch = [&](Work w) -> int {   // block = element
+    if (!w.nwork) return 0;
+    if (nt == 1)
+      hipLaunchKernelGGL(k_remap<1>, dim3(w.nwork), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order);
+    else
+      hipLaunchKernelGGL(k_remap<2>, dim3(w.nwork), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order);
+    LAUNCH_CHECK();
+    return 0;
+  };
+  if (prefetch && c->halo()) {
+    const int nq = c->qsize * NLEV;
+    hipStream_t cs = c->comm_stream;
+    hipEvent_t done = nullptr;
+    if (split_stage(c, "remap", launch, [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done))
+      return 1;
+    set_bounds_cache(c, np1_qdp);   // k_remap emitted the element min/max of the remapped field
+    c->mm_halo = np1_qdp;
+  } else {
+    Scope s(c, "remap");
+    if (launch(work_of(c, 0))) return 1;
+    set_bounds_cache(c, np1_qdp);
+  }
   return 0;
 }
 // the reference's abort condition (prim_advection_mod.F90:1323): the device flag every remap since the last check ORs into
@@ -1036,7 +1086,7 @@ static int remap_check(tse_ctx* c) {
   HIPCHK(hipMemcpyAsync(&bad, c->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(hipStreamSynchronize(c->stream));
   if (bad) {
-    c->mm_valid = 0;
+    set_bounds_cache(c, 0);
     HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
     fail("negative layer thickness.  timestep or remap time too large");
     return 2;
@@ -1044,7 +1094,7 @@ static int remap_check(tse_ctx* c) {
   return 0;
 }
 int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
-  if (remap_launch(c, dt, np1_qdp)) return 1;
+  if (remap_launch(c, dt, np1_qdp, false)) return 1;
   return remap_check(c);
 }
 
@@ -1073,7 +1123,7 @@ int tse_laplace_sphere_wk(tse_ctx* c, const double* s, double* lap) { return ele
 // level fields dp/divdp_proj/dp3d as work space (a test/utility call, not part of the time loop).
 int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp2) {
   if (!Qdp || !dp1 || !dp2) return fail("tse_remap_q_ppm: null argument");
-  c->mm_valid = 0;
+  set_bounds_cache(c, 0);
   const size_t lev = c->lev();
   double* d2 = nullptr;
   if (dalloc(&d2, lev)) return 1;
@@ -1083,7 +1133,8 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
         hipMemcpy(d2, dp2, lev * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->divdp_proj, 0, lev * 8) != hipSuccess) { rc = fail("tse_remap_q_ppm: upload failed"); break; }
     const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
     hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2);
+                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
+                       (const int*)nullptr);
     if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(Qdp, c->qdp, c->trc() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("tse_remap_q_ppm: download failed"); break; }
     rc = remap_check(c);
@@ -1133,7 +1184,7 @@ int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, c
   return 0;
 }
 int tse_dcmip_set_initial(tse_ctx* c) {
-  c->mm_valid = 0;
+  set_bounds_cache(c, 0);
   if (!c->dcmip_test) return fail("tse_dcmip_set_initial: call tse_dcmip_init first");
   Scope s(c, "dcmip");
   size_t tot = c->lev();
@@ -1161,10 +1212,10 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
     for (int r = 0; r < c->rsplit; r++) {
       if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
       if (nstep % 2 == 0) { n0 = 1; np1 = 2; } else { n0 = 2; np1 = 1; }  // TimeLevel_Qdp, time_mod.F90:85-109
-      if (tse_advec_tracers_remap_rk2(c, tstep, n0, np1)) return 1;
+      if (advec_step(c, tstep, n0, np1, r + 1 < c->rsplit)) return 1;   // (the remap follows the last one: its bounds would be stale)
       nstep++;
     }
-    if (remap_launch(c, tstep * c->rsplit, np1)) { *nstep_io = nstep; return 1; }
+    if (remap_launch(c, tstep * c->rsplit, np1, true)) { *nstep_io = nstep; return 1; }
   }
   *nstep_io = nstep;
   // the negative-thickness flag of all nsub remaps is read once: the loop above never blocks the host

@@ -1080,10 +1080,11 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
                                                          int* __restrict__ bad, double* __restrict__ mn_out,
                                                          double* __restrict__ mx_out, int force_generic, double* __restrict__ sink,
                                                          const double* __restrict__ dp2 /* null: the target grid of vertical_remap
-                                                         (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */) {
+                                                         (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */,
+                                                         const int* __restrict__ elist /* elements of this launch (null: 0..gridDim) */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
-  const int e = blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+  const int e = elist ? elist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
   if (tid == 0) S.slow = force_generic;
   // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
   for (int w = tid; w < NLEV * 16; w += nthreads) {
