@@ -122,6 +122,26 @@ def test_device_dcmip_fields_and_prim_run(ctx5, gold):
     assert relerr(elem["Qdp"][:, 0, :5], g["qdp_step6"]) < 10 * TOL_STEP
 
 
+@pytest.mark.parametrize("ne", [2, 4])
+def test_whole_step_extra_dss_variables_vs_oracle(ne):
+    """the DSS'd divdp_proj / eta_dot_dpdn / omega_p the three stages leave behind (prim_advection_mod.F90:911-960): in the
+    whole-step path they ride along as one more plane of the stage's scratch field and are assembled on read"""
+    o = po.Oracle(ne, 3, nu_q=1e19 if ne == 2 else 5e17)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    dt = 1800.0 if ne == 2 else 900.0
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+    o.dcmip_init(1)
+    for nstep in range(2):
+        hip.dcmip_step_inputs(nstep, dt); o.dcmip_step_inputs(1, nstep, dt)
+        n0 = 1 if nstep % 2 == 0 else 2
+        hip.advec_tracers_remap_rk2(dt, n0, 3 - n0); o.advec_tracers_remap_rk2(dt, nstep)
+        for name, shape in (("divdp_proj", o.divdp_proj.shape), ("eta_dot_dpdn", o.eta_dot_dpdn.shape), ("omega_p", o.omega_p.shape), ("divdp", o.divdp.shape)):
+            got, ref = hip.fetch(name, shape), getattr(o, name)
+            assert np.abs(got - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1e-300), (name, nstep)
+    hip.close(); o.close()
+
+
 def test_dcmip12_vs_reference_golden(gold):
     g = gold("ref_ne2_dcmip12.npz")
     cfg = json.loads(str(g["config"]))

@@ -98,8 +98,9 @@ struct tse_ctx {
   Scr scr() const { return Scr{tps, cse}; }
   unsigned zero0() const { return (unsigned)nslots * 16; }          // entry index of the zero slot within a chunk
   unsigned halo0() const { return (unsigned)(nslots + 1) * 16; }    // entry index of halo column 0
-  GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_) const {
-    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_};
+  GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
+                   double* var_out = nullptr, int var_out_lev = 0) const {
+    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev};
   }
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
@@ -414,9 +415,10 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   // contributions, + the received halo columns, which DSS-on-read reads from there); see tse_kernels.h
   c->tps = ((size_t)NCHUNK * c->cse * CL + 15) / 16 * 16;
   if (c->tps < (size_t)n * 16 * NLEV) return fail("tse_init: scratch plane smaller than a tracer plane");
-  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, c->qsize * c->tps) || dalloc(&c->B, c->qsize * c->tps) || dalloc(&c->C, c->qsize * c->tps))
+  const size_t scr_n = (size_t)(c->qsize + 1) * c->tps;   // qsize tracer planes + the plane of the stage's extra DSS variable
+  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, scr_n) || dalloc(&c->B, scr_n) || dalloc(&c->C, scr_n))
     return fail("tse_init: out of device memory (%zu B per tracer field, 5 fields)", trc * 8);
-  HIPCHK(hipMemset(c->T, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->B, 0, c->qsize * c->tps * 8)); HIPCHK(hipMemset(c->C, 0, c->qsize * c->tps * 8));
+  HIPCHK(hipMemset(c->T, 0, scr_n * 8)); HIPCHK(hipMemset(c->B, 0, scr_n * 8)); HIPCHK(hipMemset(c->C, 0, scr_n * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
       dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)NLEV * c->qsize) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
@@ -703,9 +705,10 @@ static int halo_exchange(tse_ctx* c, int nlyr, int kind, hipStream_t st) {
 }
 
 // ---- pack / unpack launches (on stream st) ----
-// scratch field (T or B) -> sendbuf layers [0, qsize*nlev) of nlyr_halo
-static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int nlyr_halo) {
-  const int nq = c->qsize * NLEV;
+// scratch field (T, B or C) -> sendbuf layers [0, nlyr) of nlyr_halo; nlyr = qsize*nlev (tracers) or qsize*nlev + nlev (tracers and
+// the plane of the stage's extra variable behind them: the reference's edgeAdv_p1 message, prim_advection_mod.F90:497,911-919)
+static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int nlyr_halo, int nlyr = 0) {
+  const int nq = nlyr ? nlyr : c->qsize * NLEV;
   if (!c->ncol_send) return 0;
   size_t tot = (size_t)c->ncol_send * nq;
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_send, nq, c->send_src_s, scratch,
@@ -733,9 +736,9 @@ static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr,
   return 0;
 }
 // DSS on read: copy the received tracer halo behind the planes of the scratch field the next slab kernel gathers from
-static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo) {
+static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo, int nlyr = 0) {
   if (!c->ncol_recv) return 0;
-  const int nq = c->qsize * NLEV;
+  const int nq = nlyr ? nlyr : c->qsize * NLEV;   // layers to copy: the tracer planes, or also the extra variable's plane
   size_t tot = (size_t)c->ncol_recv * nq;
   hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->scr(),
                      c->halo0());
@@ -779,9 +782,10 @@ static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
 }
 // tracer DSS pass src (scratch layout, halo columns filled) -> dst (standard layout), optionally fused with qdp_time_avg and the
 // next step's bounds; over all patches (npwork < 0) or over the patch list of a split launch
-static int dss_tracer_launch(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, const int* plist, int npwork) {
+static int dss_tracer_launch(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, const int* plist, int npwork,
+                             double* var_out = nullptr, int var_out_lev = 0) {
   if (!npwork) return 0;
-  const GatherArgs ga = c->gargs(nullptr, c->nelemd, plist, npwork);
+  const GatherArgs ga = c->gargs(nullptr, c->nelemd, plist, npwork, nullptr, 0, var_out, var_out_lev);
   const dim3 grid(patch_blocks(npwork)), blk(FLAT_THREADS);
   if (Qn0_avg)
     hipLaunchKernelGGL(k_dss_patch<1>, grid, blk, 0, c->stream, c->qsize, src, dst, Qn0_avg, (const double*)c->dp, c->qmin2, c->qmax2, ga);
@@ -791,9 +795,9 @@ static int dss_tracer_launch(tse_ctx* c, const double* src, double* dst, const d
   LAUNCH_CHECK();
   return 0;
 }
-static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg) {
+static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, double* var_out = nullptr, int var_out_lev = 0) {
   Scope s(c, "dss");
-  return dss_tracer_launch(c, src, dst, Qn0_avg, nullptr, c->npatch);
+  return dss_tracer_launch(c, src, dst, Qn0_avg, nullptr, c->npatch, var_out, var_out_lev);
 }
 
 // One euler_step of the per-stage API (prim_advection_mod.F90:667-970): every stage ends with a tracer DSS pass, because
@@ -925,7 +929,12 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   const int nq = c->qsize * NLEV;
   const dim3 blk(FLAT_THREADS);
   hipStream_t cs = c->comm_stream;
-  auto gargs = [&](const Work& w) { return c->gargs(w.order, w.nwork, w.plist, w.npwork); };
+  // the stage's extra DSS variable travels as plane qsize of the stage's scratch output and is assembled on read by the next
+  // kernel (var_in / var_out of GatherArgs): divdp_proj with stage 1, eta_dot_dpdn with stage 2, omega_p with stage 3
+  auto gargs = [&](const Work& w, const double* vin = nullptr, int vin_lev = 0, double* vout = nullptr, int vout_lev = 0) {
+    return c->gargs(w.order, w.nwork, w.plist, w.npwork, vin, vin_lev, vout, vout_lev);
+  };
+  const int nqv = nq + NLEV;   // layers of a tracer halo message with the extra variable behind the tracers
 
   // ---- stage 1 (rhs_multiplier 0, DSS extra = divdp_proj): bounds, neighbour min/max, advance Qdp(n0) -> T
   const bool halo_ready = c->halo() && c->mm_valid == n0_qdp && c->mm_halo == n0_qdp;   // prefetched by the previous step / remap
@@ -962,22 +971,20 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&](Work w) -> int {
           if (!w.nwork) return 0;
           hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(w.nwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qn0,
-                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
+                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                             gargs(w, c->divdp_proj, NLEV));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_tracers(c, cs, c->T, nq + NLEV) || pack_var(c, cs, c->divdp_proj, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
-                              unpack_halo(c, cs, c->T, nq + NLEV); })) return 1;
-  if (dss_level_var(c, &c->divdp_proj, NLEV)) return 1;
+        [&]() -> int { return pack_tracers(c, cs, c->T, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->T, nqv, nqv); })) return 1;
 
   // ---- stage 2 (rhs_multiplier 1, DSS extra = eta_dot_dpdn): T (+) edges -> B
   if (split_stage(c, "advance1",
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL((k_advance<1, 1>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->T,
-                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
+                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                             gargs(w, c->eta, NLEVP, c->divdp_proj, NLEV));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_tracers(c, cs, c->B, nq + NLEV) || pack_var(c, cs, c->eta, NLEVP) || halo_exchange(c, nq + NLEV, 0, cs) ||
-                              unpack_halo(c, cs, c->B, nq + NLEV); })) return 1;
-  if (dss_level_var(c, &c->eta, NLEVP)) return 1;
+        [&]() -> int { return pack_tracers(c, cs, c->B, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->B, nqv, nqv); })) return 1;
 
   // ---- stage 3 (rhs_multiplier 2, DSS extra = omega_p)
   // 3a: B (+) edges -> first Laplacian (pre-DSS) of the stage-2 tracers in T, element min/max (the DSS'd tracers themselves are
@@ -986,7 +993,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
-                             c->divdp_proj, c->qmin, c->qmax, (double*)nullptr, gargs(w));
+                             c->divdp_proj, c->qmin, c->qmax, (double*)nullptr, gargs(w, nullptr, 0, c->eta, NLEVP));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
                               unpack_halo(c, cs, c->T, nq); })) return 1;
@@ -996,23 +1003,22 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL((k_advance<2, 3>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->B,
-                             (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w));
+                             (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w, c->omega_p, NLEV));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_tracers(c, cs, c->C, nq + NLEV) || pack_var(c, cs, c->omega_p, NLEV) || halo_exchange(c, nq + NLEV, 0, cs) ||
-                              unpack_halo(c, cs, c->C, nq + NLEV); })) return 1;
+        [&]() -> int { return pack_tracers(c, cs, c->C, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->C, nqv, nqv); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
   if (prefetch && c->halo()) {
     hipEvent_t done = nullptr;
     if (split_stage(c, "dss",
-          [&](Work w) -> int { return dss_tracer_launch(c, c->C, Qnp1, Qn0, w.plist, w.npwork); },
+          [&](Work w) -> int { return dss_tracer_launch(c, c->C, Qnp1, Qn0, w.plist, w.npwork, c->omega_p, NLEV); },
           [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done)) return 1;
     set_bounds_cache(c, np1_qdp);
     c->mm_halo = np1_qdp;
   } else {
-    if (dss_tracer_pass(c, c->C, Qnp1, Qn0)) return 1;
+    if (dss_tracer_pass(c, c->C, Qnp1, Qn0, c->omega_p, NLEV)) return 1;
     set_bounds_cache(c, np1_qdp);
   }
-  return dss_level_var(c, &c->omega_p, NLEV);
+  return 0;
 }
 
 static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefetch) {
@@ -1227,7 +1233,7 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   struct Ent { const char* n; void* p; size_t b; };
   const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8, scr = (size_t)c->qsize * c->tps * 8;
   const size_t m2 = (size_t)2 * c->qsize * NLEV * 8;
-  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr}, {"B", c->B, scr}, {"C", c->C, scr}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
+  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr + c->tps * 8}, {"B", c->B, scr + c->tps * 8}, {"C", c->C, scr + c->tps * 8}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
                 {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
                 {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},
                 {"qmax", c->qmax, mm}, {"sendbuf", c->sendbuf, (size_t)c->ncol_send * c->nlyr_halo * 8},

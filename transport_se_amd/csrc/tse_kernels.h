@@ -231,6 +231,10 @@ struct GatherArgs {
   const unsigned* pring;           // [npatch][NRMAX] ring entry -> entry index within a chunk (slot*16+p, zero slot, halo column)
   const unsigned short* plds;      // [npatch][PS][16][3] DSS contribution -> LDS entry (own-patch point, ring entry, zero entry)
   const int* plist; int npwork;    // patch list of this launch
+  // The stage's extra DSS variable (divdp_proj / eta_dot_dpdn / omega_p, prim_advection_mod.F90:911-919,943-957) rides along as
+  // one more plane (index qsize) of the scratch fields, exactly as edgeAdv_p1 carries it behind the tracers:
+  const double* var_in;  int var_in_lev;    // producer: plane qsize of the output := spheremp * var_in[e][var_in_lev][p] (levels 0..71)
+  double* var_out;       int var_out_lev;   // consumer: rspheremp*DSS(plane qsize of the gathered input) -> var_out[e][var_out_lev][p]
 };
 constexpr int LDS_ZERO = PS * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
 struct PatchLds { double v[2][LDS_ENT][CL]; };   // 2 x 12.3 KB
@@ -338,6 +342,18 @@ __device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L
   double t3 = fma(nm, f1, v[3]); t3 = fma(em, f2, t3); t3 = fma(em, f3, t3); t3 = fma(em, f4, t3);
   out[0] = R.rs[0] * t0; out[1] = R.rs[1] * t1; out[2] = R.rs[2] * t2; out[3] = R.rs[3] * t3;
 }
+// DSS of the extra plane on read, before the tracer loop of a DSS-on-read kernel (LDS buffer 1: the loop starts on buffer 0, and
+// its barrier of tracer 0 separates these reads from the publish of tracer 1 into buffer 1).  All lanes of the block call it.
+__device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds& L, const GatherArgs& A, const double* __restrict__ src, int plane,
+                                                 int j, int k, double x[4]) {
+  GatherRaw raw;
+  double own[4];
+  gather_issue(R, A, src, plane, raw);
+  gather_publish(R, L, 1, k, raw, own);
+  lds_barrier();
+  gather_sum(R, L, 1, j, own, x);
+}
+
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
 // stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
@@ -402,6 +418,13 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
   const RowStore RS = row_store_setup(GA.S, slot, j, kc);
+  RowGather RG;
+  if (GIN) gather_setup(RG, lds_[0], GA, pid);
+  double vdss[4] = {0, 0, 0, 0};   // the previous stage's extra variable, DSS'd on read (stage 2: divdp_proj, which this stage's dp needs)
+  if (GIN && GA.var_out) {
+    gather_var_plane(RG, lds_[0], GA, Qn0, qsize, j, kc, vdss);
+    if (k < NLEV) store4(GA.var_out + ((size_t)e * GA.var_out_lev + k) * 16 + j * 4, vdss);
+  }
   // per-(e,k,row) constants, computed once and reused for every tracer:
   //   a1,a2 : metdet*Dinv*Vstar  (contravariant flux per unit Qdp: gv = a*Qdp, derivative_mod.F90:2386-2391)
   //   rm    : dt*rmetdet*rrearth ; dps = dp_star ; rdps = 1/dp_star ; c = spheremp*dp_star ; rdpk = 1/dp (RHS 1)
@@ -412,7 +435,18 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
     const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
     double dpk[4], vs1[4], vs2[4], t0[4], t1[4];
-    load4(dp + lo, dpk); load4(divdp_proj + lo, t0); load4(divdp + lo, t1);
+    load4(dp + lo, dpk); load4(divdp + lo, t1);
+    if (GIN && GA.var_out && RHS == 1) {   // divdp_proj = what was just assembled (the array is being written by this launch)
+#pragma unroll
+      for (int i = 0; i < 4; i++) t0[i] = vdss[i];
+    } else load4(divdp_proj + lo, t0);
+    if (GA.var_in) {   // this stage's extra variable, weighted, as plane qsize of the output
+      double vin[4], w[4];
+      load4(GA.var_in + ((size_t)e * GA.var_in_lev + kc) * 16 + j * 4, vin);
+#pragma unroll
+      for (int i = 0; i < 4; i++) w[i] = g.spheremp[i] * vin[i];
+      store_row_pair(Tout + (size_t)qsize * GA.S.tps, RS, kc, k < NLEV, w);
+    }
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
 #pragma unroll
@@ -449,7 +483,6 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     store_row_pair(Tout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.x);
     if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
-  RowGather RG;
   GatherRaw graw, graw2;                                 // raw own / ring loads of the gathered input(s) (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
   const double* gsrc = GIN == 2 ? lap : Qn0;             // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
@@ -461,7 +494,6 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     if (RHS == 2 && GIN < 2) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
   };
-  if (GIN) gather_setup(RG, lds_[0], GA, pid);
   if (GIN == 3 && threadIdx.x < 2 * CL) lds_[GIN == 3 ? 1 : 0].v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;
   fetch(0);
   // Memory schedule with DSS on read: wait for this tracer's own/ring loads -> publish them in LDS -> issue the previous
@@ -591,7 +623,15 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   RowGather RG;
   GatherRaw graw;
-  if (GIN) { gather_setup(RG, lds_, GA, pid); gather_issue(RG, GA, Qn0, 0, graw); }
+  if (GIN) {
+    gather_setup(RG, lds_, GA, pid);
+    if (GA.var_out) {   // the previous stage's extra variable (stage 3: eta_dot_dpdn), DSS'd on read
+      double vdss[4];
+      gather_var_plane(RG, lds_, GA, Qn0, qsize, j, kc, vdss);
+      if (k < NLEV) store4(GA.var_out + ((size_t)e * GA.var_out_lev + k) * 16 + j * 4, vdss);
+    }
+    gather_issue(RG, GA, Qn0, 0, graw);
+  }
   if (!GIN) {
     for (int q = 0; q < qsize; q++) {
       const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
@@ -726,6 +766,11 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_dss_patch(int qsize, const dou
       cur.mx = quad_max(fmax(fmax(y[0], y[1]), fmax(y[2], y[3])));
     }
   };
+  if (GA.var_out) {   // the last stage's extra variable (omega_p), DSS'd on read
+    double vdss[4];
+    gather_var_plane(RG, lds_, GA, src, qsize, j, kc, vdss);
+    if (k < NLEV) store4(GA.var_out + ((size_t)e * GA.var_out_lev + k) * 16 + j * 4, vdss);
+  }
   fetch(0);
   Out A, B;
   step(0, nullptr, A);
