@@ -142,6 +142,31 @@ def test_whole_step_extra_dss_variables_vs_oracle(ne):
     hip.close(); o.close()
 
 
+def test_level_variables_same_bits_through_both_routes():
+    """divdp_proj / eta_dot_dpdn / omega_p do not depend on the tracers, so the whole-step route (extra plane assembled on read)
+    and the one-DSS-pass-per-stage route (k_dss_lvl) must leave exactly the same bits"""
+    o = po.Oracle(4, 3, nu_q=5e17)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    names = ("divdp_proj", "eta_dot_dpdn", "omega_p")
+    out = {}
+    for route in ("1", "0"):
+        os.environ["TSE_DSS_ON_READ"] = route
+        try:
+            hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+            for nstep in range(2):
+                hip.dcmip_step_inputs(nstep, 900.0)
+                n0 = 1 if nstep % 2 == 0 else 2
+                hip.advec_tracers_remap_rk2(900.0, n0, 3 - n0)
+                out[(route, nstep)] = {n_: hip.fetch(n_, getattr(o, n_).shape).copy() for n_ in names}
+        finally:
+            os.environ.pop("TSE_DSS_ON_READ", None)
+    for nstep in range(2):
+        for n_ in names:
+            assert np.array_equal(out[("1", nstep)][n_], out[("0", nstep)][n_]), (n_, nstep)
+    hip.close(); o.close()
+
+
 def test_dcmip12_vs_reference_golden(gold):
     g = gold("ref_ne2_dcmip12.npz")
     cfg = json.loads(str(g["config"]))

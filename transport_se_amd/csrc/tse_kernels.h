@@ -789,6 +789,9 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const 
                                                               const double* __restrict__ spheremp, const double* __restrict__ src, int src_lev,
                                                               double* __restrict__ dst, int dst_lev, const double* __restrict__ recvbuf,
                                                               int nlyr_halo, int lyr0, const int* __restrict__ order) {
+  // spheremp*var is a stored (rounded) product in the reference (prim_advection_mod.F90:913-918) and in the whole-step path's extra
+  // plane, so the products below must not be contracted into the sums that follow: both routes then leave the same bits
+#pragma clang fp contract(off)
   const DssLane ln = dss_lane<LVL_UNITS>(nelemd);
   if (!ln.live) return;
   const int e = order[ln.slot], k = ln.r >> 2, j = ln.r & 3;   // the lane does levels k and k + NLEV/2 (the table lookup is shared)
