@@ -154,6 +154,16 @@ def main():
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (start N>1 ranks with `python bench.py --gpus N` or "
                          "`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)" % (a.gpus, world))
+    # a rank stuck in communicator set-up or in a halo exchange whose peer died would otherwise block the job for ever
+    limit = float(os.environ.get("TSE_BENCH_WATCHDOG_S", "1800"))
+    watchdog = None
+    if limit > 0:
+        import threading
+
+        def give_up():
+            print("bench.py: rank %d has no result after %g s (TSE_BENCH_WATCHDOG_S): giving up" % (rank, limit), file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(limit, give_up); watchdog.daemon = True; watchdog.start()
     import torch
     import torch.distributed as dist
     # TSE_EXCHANGE: "rccl" (default: in-library RCCL send/recv), "torch" (torch.distributed P2P in the exchange callback),
@@ -198,6 +208,8 @@ def main():
         cs = torch.tensor([checksum], dtype=torch.int64, device=dev)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         checksum = int(cs.item())
+    if watchdog:
+        watchdog.cancel()
     ktimes = {k: run.hip.kernel_time(k) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap", "level", "dcmip", "avg")}
     run.hip.timing(False)
     if rank == 0:
@@ -222,6 +234,7 @@ def main():
                        "rank_boundary_elements": nb, "interior_elements": ni},
             # what the communicator itself reports (ncclCommCount / ncclCommUserRank); 1 / "none" on a single GPU
             "world_size": comm_world if run.exchange_kind == "rccl" else world, "exchange": run.exchange_kind,
+            **({"exchange_note": run.exchange_note} if run.exchange_note else {}),
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_ms": ms / max(n, 1), "launches": n,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,

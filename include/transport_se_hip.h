@@ -97,6 +97,9 @@ int tse_comm_unique_id(void *id_out /* TSE_COMM_ID_BYTES */);
 int tse_comm_init(tse_ctx *ctx, const void *id /* TSE_COMM_ID_BYTES */, int rank, int nranks);
 /* rank / size as the communicator itself reports them (ncclCommUserRank/ncclCommCount); 0/1 without a communicator */
 int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
+/* give the communicator up (ncclCommAbort; no-op without one): afterwards the halo goes through the exchange callback of
+ * tse_init_args again.  For a host that found tse_comm_init failing on some rank and falls back to its own transport. */
+int tse_comm_abort(tse_ctx *ctx);
 /* number of local elements that touch another rank (computed first in every stage) and that do not */
 int tse_boundary_layout(tse_ctx *ctx, int *n_boundary, int *n_interior);
 

@@ -133,3 +133,48 @@ def test_halo_exchange_on_rccl_self_peer():
         assert torch.equal(recv[:5 * nlyr], send[:5 * nlyr]) and not recv[5 * nlyr:].any()
     finally:
         dist.destroy_process_group()
+
+
+_FALLBACK_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+torch.cuda.set_device(0)
+dist.init_process_group("gloo")
+from transport_se_amd.driver import PrimRun
+r = PrimRun(4, 2, rank=dist.get_rank(), world=dist.get_world_size(), device=0, dist_mod=dist, torch_mod=torch, exchange="rccl")
+np1 = r.run(3)
+cs = torch.tensor([r.state_checksum(np1, torch)], dtype=torch.int64)
+dist.all_reduce(cs)
+if dist.get_rank() == 0:
+    print("RESULT " + json.dumps({"exchange": r.exchange_kind, "note": r.exchange_note, "checksum": int(cs.item()), "comm": r.hip.comm_info()}), flush=True)
+r.close()
+dist.destroy_process_group()
+'''
+
+
+def test_ranks_that_cannot_build_a_communicator_fall_back_together(tmp_path):
+    """exchange="rccl" with two ranks on ONE device: ncclCommInitRank refuses the duplicate GPU on both.  The driver must not
+    hang or leave half the ranks on RCCL: all ranks drop to the host-staged callback, say so, and the result has the bits of
+    the single-rank run."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from transport_se_amd.driver import PrimRun
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = PrimRun(4, 2, device=0, torch_mod=torch)
+    ref = one.state_checksum(one.run(3), torch)
+    one.close()
+    w = tmp_path / "worker.py"
+    w.write_text(_FALLBACK_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", str(w), root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out + r.stderr.decode()[-2000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["exchange"] == "staged" and "RCCL communicator could not be initialised" in res["note"]
+    assert res["comm"] == [0, 1]                      # no communicator left behind
+    assert b"WARNING: RCCL communicator" in r.stderr
+    assert res["checksum"] == ref

@@ -523,7 +523,14 @@ int tse_comm_init(tse_ctx* c, const void* id_in, int rank, int nranks) {
   HIPCHK(hipSetDevice(c->device));
   ncclUniqueId id;
   memcpy(&id, id_in, sizeof id);
-  NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+  ncclComm_t cm = nullptr;
+  NCCLCHK(ncclCommInitRank(&cm, nranks, id, rank));   // on failure the context keeps its callback route (c->comm stays null)
+  c->comm = cm;
+  return 0;
+}
+int tse_comm_abort(tse_ctx* c) {
+  if (!c) return fail("tse_comm_abort: null context");
+  if (c->comm) { (void)ncclCommAbort(c->comm); c->comm = nullptr; }
   return 0;
 }
 int tse_comm_info(tse_ctx* c, int* rank, int* nranks) {

@@ -132,12 +132,15 @@ class PrimRun:
                          putmapP=desc["putmapP"], getmapP=desc["getmapP"], reverse=desc["reverse"])
         self.lat, self.lon = geo["lat"][mine], geo["lon"][mine]
         callback = None
-        if world > 1 and exchange != "rccl":
-            if exchange not in ("torch", "staged"):
+        if world > 1:
+            if exchange not in ("rccl", "torch", "staged"):
                 raise ValueError("exchange=%r" % (exchange,))
-            callback = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod, stage_through_host=(exchange == "staged"))
+            # with "rccl" the callback stays dormant: it is the transport of last resort when the communicator cannot be
+            # built on some rank (see below), and is never entered while the library holds a communicator
+            callback = HaloExchange(desc, "cuda:%d" % device, dist_mod, torch_mod, stage_through_host=(exchange != "torch"))
         self._exchange = callback
         self.exchange_kind = exchange if world > 1 else "none"
+        self.exchange_note = None
         self.hip_device = device
         self.rank, self.world = rank, world
         self.hip = HipMod(self.elem, cm.dvv(), (self.hv.hyai, self.hv.hybi, self.hv.ps0), qsize, self.nu_q,
@@ -147,7 +150,23 @@ class PrimRun:
             if exchange == "rccl":
                 box = [HipMod.comm_unique_id() if rank == 0 else None]
                 dist_mod.broadcast_object_list(box, src=0)
-                self.hip.comm_init(box[0], rank, world)
+                err = None
+                try:
+                    self.hip.comm_init(box[0], rank, world)
+                except RuntimeError as ex:
+                    err = str(ex)
+                errs = [None] * world
+                dist_mod.all_gather_object(errs, err)
+                bad = [(r, e) for r, e in enumerate(errs) if e]
+                if bad:
+                    # every rank leaves RCCL together and says so: host-staged slots over the control-plane backend
+                    self.hip.comm_abort()
+                    self.exchange_kind = "staged"
+                    self.exchange_note = "RCCL communicator could not be initialised on rank(s) %s (%s): halo staged through the host" \
+                                         % (",".join(str(r) for r, _ in bad), bad[0][1])
+                    if rank == 0:
+                        import sys
+                        print("WARNING: " + self.exchange_note, file=sys.stderr, flush=True)
         self.hip.dcmip_init(test_case, self.lat, self.lon, self.hv.hyam, self.hv.hybm)
         self.hip.dcmip_set_initial()
         self.nstep = 0

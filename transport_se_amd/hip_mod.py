@@ -101,6 +101,10 @@ class HipMod:
         assert len(comm_id) == _lib.COMM_ID_BYTES
         self._chk(self.L.tse_comm_init(self.h, C.c_char_p(comm_id), int(rank), int(nranks)))
 
+    def comm_abort(self):
+        """drop the communicator (if any): the halo goes through the exchange callback again"""
+        self._chk(self.L.tse_comm_abort(self.h))
+
     def comm_info(self):
         r, n = C.c_int(), C.c_int()
         self._chk(self.L.tse_comm_info(self.h, C.byref(r), C.byref(n)))
