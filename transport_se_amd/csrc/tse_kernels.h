@@ -897,6 +897,7 @@ struct RemapLds {
   double z2[NLEV][16];
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
+  double dA[NLEV], dB[NLEV];       // hyai(k+1)-hyai(k), hybi(k+1)-hybi(k)
   int slow;                        // some column has kid(k) outside {k, k+1}
 };
 __device__ __forceinline__ double ppm_dma(double d0, double d1, double d2, double am, double a0, double ap) {
@@ -1143,25 +1144,49 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     S.dpn[w >> 4][w & 15] = 1.0 / dp[o];   // Q = Qdp * (1/dp), as k_advance forms its local bounds
     if (d < 0) atomicOr(bad, 1);
   }
+  if (tid < NLEV) { S.dA[tid] = hyai[tid + 1] - hyai[tid]; S.dB[tid] = hybi[tid + 1] - hybi[tid]; }
   __syncthreads();
   if (tid < 16) {
+    // The column scans keep the reference's serial order (their roundings are part of the result), so 16 lanes do them; what
+    // can be taken off the dependency chain is everything but the adds: the layers are fetched from LDS a dozen at a time
+    // (one latency per batch instead of one per level), and sum(dp3d) of ps_v (:1313) IS the last old-grid interface
+    // pressure pio(nlev+1) (:142-144: the same terms added in the same order from 0), so it is not summed a second time; the
+    // hybrid coefficient differences of the target grid (:1316-1317) wait in LDS instead of behind one scalar load per level.
     const int p = tid;
-    double s = 0.0;
-    for (int k = 0; k < NLEV; k++) s += S.dpo[k + 2][p];
-    double ps = hyai[0] * ps0 + s;
-    ps_v[(size_t)e * 16 + p] = ps;
-    double pio_prev = 0.0;
+    constexpr int SB = 12;
+    static_assert(NLEV % SB == 0, "scan batches");
+    double run = 0.0;
     S.pio[0][p] = 0.0;
-    for (int k = 1; k <= NLEV; k++) { pio_prev = pio_prev + S.dpo[k + 1][p]; S.pio[k][p] = pio_prev; }
+    for (int kb = 0; kb < NLEV; kb += SB) {
+      double d[SB];
+#pragma unroll
+      for (int i = 0; i < SB; i++) d[i] = S.dpo[kb + i + 2][p];
+#pragma unroll
+      for (int i = 0; i < SB; i++) { run = run + d[i]; S.pio[kb + i + 1][p] = run; }
+    }
+    const double pio_prev = run;
+    const double ps = fma(hyai[0], ps0, run);
+    ps_v[(size_t)e * 16 + p] = ps;
     S.pio[NLEV + 1][p] = pio_prev + 1.;
     for (int k = 1; k <= 2; k++) { S.dpo[2 - k][p] = S.dpo[k + 1][p]; S.dpo[NLEV + k + 1][p] = S.dpo[NLEV + 2 - k][p]; }
     // new-grid interface pressures pin(k+1) (serial sum, as the reference's :150-158), parked in z2's slot until the
     // bracket search below replaces them
     double pin = 0.0;
-    for (int k = 1; k <= NLEV; k++) {
-      double dpn = dp2 ? dp2[((size_t)e * NLEV + k - 1) * 16 + p] : (hyai[k] - hyai[k - 1]) * ps0 + (hybi[k] - hybi[k - 1]) * ps;
-      pin = pin + dpn;
-      S.z2[k - 1][p] = (k == NLEV) ? pio_prev : pin;  // pin(nlev+1) = pio(nlev+1)
+    for (int kb = 0; kb < NLEV; kb += SB) {
+      double d[SB];
+      if (dp2) {
+#pragma unroll
+        for (int i = 0; i < SB; i++) d[i] = dp2[((size_t)e * NLEV + kb + i) * 16 + p];
+      } else {
+#pragma unroll
+        for (int i = 0; i < SB; i++) d[i] = fma(S.dA[kb + i], ps0, __dmul_rn(S.dB[kb + i], ps));   // dA*ps0 + dB*ps, one rounding of the sum
+      }
+#pragma unroll
+      for (int i = 0; i < SB; i++) {
+        const int k = kb + i + 1;
+        pin = pin + d[i];
+        S.z2[k - 1][p] = (k == NLEV) ? pio_prev : pin;  // pin(nlev+1) = pio(nlev+1)
+      }
     }
   }
   __syncthreads();
