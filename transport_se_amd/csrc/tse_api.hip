@@ -758,9 +758,8 @@ static int nbr_minmax_kernel(tse_ctx* c) {
   const int m = c->qsize * NLEV;
   {
     Scope s(c, "minmax");
-    hipLaunchKernelGGL(k_nbr_minmax, dim3(8 * ((c->nelemd + 7) / 8)), dim3(512), 0, c->stream,   // 512 lanes: 2.4 ms per launch, 256: 2.5
- c->nelemd, c->qsize, c->nbr, c->qmin,
-                       c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m, c->order);
+    hipLaunchKernelGGL(k_nbr_minmax_patch<8>, dim3(nbr_patch_blocks(c->npatch, c->qsize)), dim3(512), 0, c->stream, c->npatch, c->qsize, c->nbr,
+                       c->pslots, c->slot_of, c->qmin, c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m);
     LAUNCH_CHECK();
   }
   std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);

@@ -163,37 +163,65 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
 // neighbor_minmax / min-max half of biharmonic_wk_scalar_minmax (viscosity_mod.F90:748-816,389-432):
 // min/max over the element and its <= 8 neighbours.  nbr[e][8]: >= 0 local element, -1 none,
 // <= -2 remote: column -(v+2) of the received halo (layer index = (q*NLEV+k), min set then max set).
-__global__ __launch_bounds__(512) void k_nbr_minmax(int nelemd, int qsize, const int* __restrict__ nbr,
-                                                    const double* __restrict__ in_min, const double* __restrict__ in_max,
-                                                    double* __restrict__ out_min, double* __restrict__ out_max,
-                                                    const double* __restrict__ recvbuf, int nlyr_halo, const int* __restrict__ order) {
-  // block = element; the 8 XCDs each walk a contiguous range of elements in the strip order of tse_api.hip (the same the
-  // DSS kernels use), so that an element's bounds are re-read by its neighbours -- west/east one block, south/north
-  // about eight blocks later -- out of the same L2 (every value is needed by up to 9 elements; 40 KB per element)
-  const int S8 = (nelemd + 7) >> 3;
-  const int slot = (blockIdx.x & 7) * S8 + (blockIdx.x >> 3);
-  if (slot >= nelemd) return;
-  const int e = order[slot];
+// Block = (patch of the scratch layout, tile of 64 level-pair entries); a wave serves two element slots.  Each wave publishes
+// its elements' tiles in LDS; of the 8 neighbours of an element two thirds (84 of 128 in a full 4x4 patch) are slots of the
+// same patch and come from there, the rest -- other patches, the received halo -- from global memory.  The neighbour
+// structure is wave-uniform (scalar loads and branches).  8 GB per launch at ne120/q35: 1.9 ms; one element per block with all
+// 8 neighbours from global memory (L2) took 2.45 ms, 16 waves with one slot each 2.15, 4 waves with four slots 2.0.
+constexpr int MM_TILE = 64;
+inline int nbr_patch_blocks(int npatch, int qsize) { return 8 * ((npatch + 7) / 8) * ((qsize * NLEV / 2 + MM_TILE - 1) / MM_TILE); }
+template <int WB /* waves per block; a wave serves PS / WB element slots */>
+__global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qsize, const int* __restrict__ nbr, const int* __restrict__ pslots,
+                                                             const int* __restrict__ slot_of, const double* __restrict__ in_min,
+                                                             const double* __restrict__ in_max, double* __restrict__ out_min,
+                                                             double* __restrict__ out_max, const double* __restrict__ recvbuf, int nlyr_halo) {
+  __shared__ double2 smn[PS][MM_TILE], smx[PS][MM_TILE];
+  constexpr int R = PS / WB;
   const int m = qsize * NLEV;
-  const double *pmn[8], *pmx[8];
+  // the 8 XCDs each take a contiguous range of patches and walk it tile by tile: the patches whose elements a block reads
+  // from global memory ran the same tile on the same XCD a few blocks earlier
+  const int npx = (npatch + 7) >> 3, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int tile = i / npx, pi = x * npx + (i - tile * npx);
+  if (pi >= npatch) return;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int l = 2 * (tile * MM_TILE + lane);
+  const bool inr = l < m;   // m is even: l + 1 < m as well
+  int e[R];
+  double2 mn[R], mx[R];
 #pragma unroll
-  for (int d = 0; d < 8; d++) {
-    const int n = nbr[e * 8 + d];
-    pmn[d] = n >= 0 ? in_min + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo : in_min + (size_t)e * m);
-    pmx[d] = n >= 0 ? in_max + (size_t)n * m : (n <= -2 ? recvbuf + (size_t)(-(n + 2)) * nlyr_halo + m : in_max + (size_t)e * m);
+  for (int r = 0; r < R; r++) {
+    e[r] = __builtin_amdgcn_readfirstlane(pslots[pi * PS + w + r * WB]);   // -1: hole
+    mn[r] = make_double2(0., 0.); mx[r] = mn[r];
+    if (e[r] >= 0 && inr) { mn[r] = *reinterpret_cast<const double2*>(in_min + (size_t)e[r] * m + l); mx[r] = *reinterpret_cast<const double2*>(in_max + (size_t)e[r] * m + l); }
   }
-  // two consecutive entries per lane: 16-byte loads/stores (m = qsize*72 is even; so are the halo offsets)
-  for (int l = 2 * threadIdx.x; l < m; l += 2 * blockDim.x) {
-    double2 mn = *reinterpret_cast<const double2*>(in_min + (size_t)e * m + l), mx = *reinterpret_cast<const double2*>(in_max + (size_t)e * m + l);
-    double2 nmn[8], nmx[8];   // all 16 neighbour loads in flight together
 #pragma unroll
-    for (int d = 0; d < 8; d++) { nmn[d] = *reinterpret_cast<const double2*>(pmn[d] + l); nmx[d] = *reinterpret_cast<const double2*>(pmx[d] + l); }
+  for (int r = 0; r < R; r++) { smn[w + r * WB][lane] = mn[r]; smx[w + r * WB][lane] = mx[r]; }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    if (e[r] < 0) continue;
+    const bool on = inr;
+    double2 nmn[8], nmx[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-      mn.x = fmin(mn.x, nmn[d].x); mn.y = fmin(mn.y, nmn[d].y);
-      mx.x = fmax(mx.x, nmx[d].x); mx.y = fmax(mx.y, nmx[d].y);
+      const int n = nbr[e[r] * 8 + d];   // wave-uniform
+      nmn[d] = mn[r]; nmx[d] = mx[r];    // no neighbour in this direction
+      if (n >= 0) {
+        const int sl = slot_of[n];
+        if (sl / PS == pi) { nmn[d] = smn[sl - pi * PS][lane]; nmx[d] = smx[sl - pi * PS][lane]; }
+        else if (on) { nmn[d] = *reinterpret_cast<const double2*>(in_min + (size_t)n * m + l); nmx[d] = *reinterpret_cast<const double2*>(in_max + (size_t)n * m + l); }
+      } else if (n <= -2 && on) {
+        const double* h = recvbuf + (size_t)(-(n + 2)) * nlyr_halo + l;
+        nmn[d] = *reinterpret_cast<const double2*>(h); nmx[d] = *reinterpret_cast<const double2*>(h + m);
+      }
     }
-    *reinterpret_cast<double2*>(out_min + (size_t)e * m + l) = mn; *reinterpret_cast<double2*>(out_max + (size_t)e * m + l) = mx;
+    double2 a = mn[r], b = mx[r];
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      a.x = fmin(a.x, nmn[d].x); a.y = fmin(a.y, nmn[d].y);
+      b.x = fmax(b.x, nmx[d].x); b.y = fmax(b.y, nmx[d].y);
+    }
+    if (on) { *reinterpret_cast<double2*>(out_min + (size_t)e[r] * m + l) = a; *reinterpret_cast<double2*>(out_max + (size_t)e[r] * m + l) = b; }
   }
 }
 
