@@ -714,12 +714,18 @@ static int halo_exchange(tse_ctx* c, int nlyr, int kind, hipStream_t st) {
 // ---- pack / unpack launches (on stream st) ----
 // scratch field (T, B or C) -> sendbuf layers [0, nlyr) of nlyr_halo; nlyr = qsize*nlev (tracers) or qsize*nlev + nlev (tracers and
 // the plane of the stage's extra variable behind them: the reference's edgeAdv_p1 message, prim_advection_mod.F90:497,911-919)
+// 32-bit work-item indices in the pack / unpack kernels
+static int halo_items(size_t tot, unsigned* blocks) {
+  if (tot >= ((size_t)1 << 32)) return fail("halo pack: %zu work items", tot);
+  *blocks = (unsigned)((tot + 255) / 256);
+  return 0;
+}
 static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int nlyr_halo, int nlyr = 0) {
   const int nq = nlyr ? nlyr : c->qsize * NLEV;
   if (!c->ncol_send) return 0;
-  size_t tot = (size_t)c->ncol_send * nq;
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_send, nq, c->send_src_s, scratch,
-                     (const double*)nullptr, c->sendbuf, nlyr_halo, 0, c->scr(), 0);
+  unsigned nb;
+  if (halo_items((size_t)c->ncol_send * (nq / CL), &nb)) return 1;
+  hipLaunchKernelGGL(k_pack_scratch, dim3(nb), dim3(256), 0, st, c->ncol_send, nq / CL, c->send_src_s, scratch, c->sendbuf, nlyr_halo, c->scr());
   LAUNCH_CHECK();
   return 0;
 }
@@ -727,17 +733,18 @@ static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int n
 static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_levels) {
   const int nq = c->qsize * NLEV;
   if (!c->ncol_send || !var) return 0;
-  size_t tv = (size_t)c->ncol_send * NLEV;
-  hipLaunchKernelGGL(k_pack, dim3((unsigned)((tv + 255) / 256)), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var,
-                     c->spheremp, c->sendbuf, nq + NLEV, nq, Scr{0, 0}, var_levels);
+  unsigned nb;
+  if (halo_items((size_t)c->ncol_send * NLEV, &nb)) return 1;
+  hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var, c->spheremp, c->sendbuf, nq + NLEV, nq, var_levels);
   LAUNCH_CHECK();
   return 0;
 }
 static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr, const double* qmax = nullptr) {
   const int m = c->qsize * NLEV;
   if (!c->nmm_send) return 0;
-  size_t tot = (size_t)c->nmm_send * m;
-  hipLaunchKernelGGL(k_pack_minmax, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
+  unsigned nb;
+  if (halo_items((size_t)c->nmm_send * (m / 2), &nb)) return 1;
+  hipLaunchKernelGGL(k_pack_minmax, dim3(nb), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
                      qmin ? qmin : (const double*)c->qmin, qmax ? qmax : (const double*)c->qmax, c->sendbuf_mm, 2 * m, 0);
   LAUNCH_CHECK();
   return 0;
@@ -746,9 +753,9 @@ static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr,
 static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo, int nlyr = 0) {
   if (!c->ncol_recv) return 0;
   const int nq = nlyr ? nlyr : c->qsize * NLEV;   // layers to copy: the tracer planes, or also the extra variable's plane
-  size_t tot = (size_t)c->ncol_recv * nq;
-  hipLaunchKernelGGL(k_unpack_halo, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->ncol_recv, nq, c->recvbuf, nlyr_halo, field, c->scr(),
-                     c->halo0());
+  unsigned nb;
+  if (halo_items((size_t)c->ncol_recv * (nq / CL), &nb)) return 1;
+  hipLaunchKernelGGL(k_unpack_halo, dim3(nb), dim3(256), 0, st, c->ncol_recv, nq / CL, c->recvbuf, nlyr_halo, field, c->scr(), c->halo0());
   LAUNCH_CHECK();
   return 0;
 }

@@ -400,12 +400,18 @@ __device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[
   }
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
-__global__ void k_unpack_halo(int ncol, int nq /* qsize*NLEV */, const double* __restrict__ recvbuf, int nlyr_halo, double* __restrict__ dst,
-                              Scr S, unsigned halo0 /* entry index of halo column 0 within a chunk */) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)ncol * nq) return;
-  const int col = (int)(t / nq), l = (int)(t % nq), q = l / NLEV, k = l - q * NLEV;
-  dst[(size_t)q * S.tps + ((size_t)(k / CL) * S.cse + halo0 + col) * CL + (k % CL)] = recvbuf[(size_t)col * nlyr_halo + l];
+// thread = (one chunk of one plane, halo column), columns fastest: a chunk's halo columns are contiguous in the scratch layout
+// (32 bytes each), so the stores are whole lines; the loads are 32-byte pieces of the [col][layer] buffer
+__global__ void k_unpack_halo(int ncol, int ng /* layers / CL: (tracer or extra-variable plane, chunk) pairs */, const double* __restrict__ recvbuf,
+                              int nlyr_halo, double* __restrict__ dst, Scr S, unsigned halo0 /* entry index of halo column 0 within a chunk */) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ncol * (unsigned)ng) return;
+  const unsigned g = t / (unsigned)ncol, col = t - g * (unsigned)ncol, q = g / NCHUNK, kc = g - q * NCHUNK;
+  const double* in = recvbuf + (size_t)col * nlyr_halo + (size_t)g * CL;   // layer q*NLEV + kc*CL
+  double* out = dst + (size_t)q * S.tps + ((size_t)kc * S.cse + halo0 + col) * CL;
+  static_assert(CL == 4, "two 16-byte moves per chunk entry");
+  const double2 a = *reinterpret_cast<const double2*>(in), b = *reinterpret_cast<const double2*>(in + 2);
+  *reinterpret_cast<double2*>(out) = a; *reinterpret_cast<double2*>(out + 2) = b;
 }
 // the all-zero slot of every chunk of every plane (after a caller used the scratch field as a plain buffer)
 __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned zero0 /* entry index of the zero slot */) {
@@ -877,25 +883,38 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const 
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
-                       Scr S /* S.tps > 0: src is a scratch field and send_src holds {slot, position}, instead of [e][lyr][p] and {element, point} */,
-                       int src_lyr /* layers per element of a plain src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)ncol * nlyr) return;
-  int col = (int)(t / nlyr), l = (int)(t % nlyr);
-  int2 s = send_src[col];
-  double a = S.tps ? src[t_idx(S, l / NLEV, s.x, s.y, l % NLEV)] : src[((size_t)s.x * src_lyr + l) * 16 + s.y];
+                       int src_lyr /* layers per element of src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ncol * (unsigned)nlyr) return;
+  const unsigned col = t / (unsigned)nlyr, l = t - col * (unsigned)nlyr;
+  const int2 s = send_src[col];
+  double a = src[((size_t)s.x * src_lyr + l) * 16 + s.y];
   if (scale_in) a = scale_in[(size_t)s.x * 16 + s.y] * a;
   sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = a;
 }
-// element-constant min/max fields packed the way neighbor_minmax does (viscosity_mod.F90:764-774)
-__global__ void k_pack_minmax(int ncol, int m, const int2* __restrict__ send_src, const double* __restrict__ qmin,
+// the same from a scratch field (send_src_s[col] = {slot, position}): thread = (column, chunk of a plane) moves the chunk's
+// 4 levels -- 32 contiguous bytes on both sides -- layers fastest, so the stores are whole lines
+__global__ void k_pack_scratch(int ncol, int ng /* layers / CL */, const int2* __restrict__ send_src_s, const double* __restrict__ src,
+                               double* __restrict__ sendbuf, int nlyr_halo, Scr S) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (unsigned)ncol * (unsigned)ng) return;
+  const unsigned col = t / (unsigned)ng, g = t - col * (unsigned)ng, q = g / NCHUNK, kc = g - q * NCHUNK;
+  const int2 sp = send_src_s[col];
+  const double* in = src + (size_t)q * S.tps + ((size_t)kc * S.cse + (size_t)sp.x * 16 + sp.y) * CL;
+  double* out = sendbuf + (size_t)col * nlyr_halo + (size_t)g * CL;
+  const double2 a = *reinterpret_cast<const double2*>(in), b = *reinterpret_cast<const double2*>(in + 2);
+  *reinterpret_cast<double2*>(out) = a; *reinterpret_cast<double2*>(out + 2) = b;
+}
+// element-constant min/max fields packed the way neighbor_minmax does (viscosity_mod.F90:764-774); two entries per thread
+__global__ void k_pack_minmax(int ncol, int m /* even */, const int2* __restrict__ send_src, const double* __restrict__ qmin,
                               const double* __restrict__ qmax, double* __restrict__ sendbuf, int nlyr_halo, int lyr0) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)ncol * m) return;
-  int col = (int)(t / m), l = (int)(t % m);
-  int e = send_src[col].x;
-  sendbuf[(size_t)col * nlyr_halo + lyr0 + l] = qmin[(size_t)e * m + l];
-  sendbuf[(size_t)col * nlyr_halo + lyr0 + m + l] = qmax[(size_t)e * m + l];
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, h = (unsigned)m / 2;
+  if (t >= (unsigned)ncol * h) return;
+  const unsigned col = t / h, l = 2 * (t - col * h);
+  const int e = send_src[col].x;
+  double* out = sendbuf + (size_t)col * nlyr_halo + lyr0 + l;
+  *reinterpret_cast<double2*>(out) = *reinterpret_cast<const double2*>(qmin + (size_t)e * m + l);
+  *reinterpret_cast<double2*>(out + m) = *reinterpret_cast<const double2*>(qmax + (size_t)e * m + l);
 }
 
 // qdp_time_avg alone (prim_advection_mod.F90:645-662), for the stage-by-stage API
