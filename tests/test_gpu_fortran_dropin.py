@@ -73,3 +73,25 @@ def test_reference_hooks_multirank_mpi_exchange(gold, nranks, whole_step):
     assert seen == q.shape[0]
     err = np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max()
     assert err < 5e-12, err
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(MPIEXEC)), reason="Fortran drop-in harness not built")
+def test_rccl_mode_falls_back_to_the_mpi_exchange_when_the_communicator_cannot_be_built(gold):
+    """TSE_EXCHANGE=rccl on 2 MPI ranks that share the one GPU: ncclCommInitRank refuses the duplicate device on both ranks;
+    cuda_mod_init must agree on that over MPI, drop the communicators and carry on with the MPI body of bndry_exchangeV --
+    same output as the plain run -- instead of aborting or hanging."""
+    g = gold("ref_ne2_dcmip11.npz")
+    cfg = json.loads(str(g["config"]))
+    out = tempfile.mkdtemp(prefix="tse_f90fb_")
+    stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
+                                                 out, os.path.join(ROOT, "tests", "golden", "vcoord"))
+    res = subprocess.run([MPIEXEC, "-n", "2", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                         env=dict(_env(True), TSE_EXCHANGE="rccl"))
+    log = res.stdout.decode()
+    assert "RCCL communicator could not be initialised" in log, log[-3000:]
+    assert "ref_harness done" in log, log[-3000:]
+    q = np.empty_like(g["qdp_step6"])
+    for r in range(2):
+        st = po.read_static(os.path.join(out, "static_000000_r%04d.bin" % r))
+        q[st["gid"] - 1] = po.read_state(os.path.join(out, "state_000006_r%04d.bin" % r))["qdp"]
+    assert np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max() < 5e-12

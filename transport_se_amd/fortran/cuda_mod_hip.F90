@@ -62,6 +62,9 @@ module cuda_mod
      integer(c_int) function tse_comm_unique_id(id) bind(C, name='tse_comm_unique_id')
        import; type(c_ptr), value :: id
      end function
+     integer(c_int) function tse_comm_abort(ctx) bind(C, name='tse_comm_abort')
+       import; type(c_ptr), value :: ctx
+     end function
      integer(c_int) function tse_comm_init(ctx, id, rank, nranks) bind(C, name='tse_comm_init')
        import; type(c_ptr), value :: ctx, id; integer(c_int), value :: rank, nranks
      end function
@@ -163,7 +166,7 @@ contains
     type(derivative_t), intent(in) :: deriv
     type(hvcoord_t),    intent(in) :: hvcoord
     type(tse_init_args) :: a
-    integer :: ie, j, ns, nr, e2, ierr
+    integer :: ie, j, ns, nr, e2, ierr, rc_comm, rc_any
     integer(c_int) :: ncs, ncr
     character(len=16) :: xmode
     logical :: use_rccl
@@ -209,7 +212,8 @@ contains
     ! own stream -- the communicator id travels over MPI once, below; otherwise the MPI body of tse_f_exchange is the callback
     call get_environment_variable('TSE_EXCHANGE', xmode)
     use_rccl = (trim(xmode) == 'rccl') .and. hybrid%par%nprocs > 1
-    if (ns + nr > 0 .and. .not. use_rccl) a%exchange = c_funloc(tse_f_exchange)
+    ! (with rccl the MPI body stays registered but dormant: the transport of last resort if the communicator cannot be built)
+    if (ns + nr > 0) a%exchange = c_funloc(tse_f_exchange)
     call get_environment_variable('TSE_DEVICE_PER_RANK', xmode)
     if (trim(xmode) == '1') a%device = hybrid%par%rank        ! single node: MPI rank r drives GPU r
     call check(tse_init(ctx, a), 'cuda_mod_init')
@@ -222,7 +226,12 @@ contains
     if (use_rccl) then
        if (hybrid%par%rank == 0) call check(tse_comm_unique_id(c_loc(comm_id)), 'tse_comm_unique_id')
        call MPI_Bcast(comm_id, 128, MPI_CHARACTER, 0, hybrid%par%comm, ierr)
-       call check(tse_comm_init(ctx, c_loc(comm_id), int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int)), 'tse_comm_init')
+       rc_comm = tse_comm_init(ctx, c_loc(comm_id), int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int))
+       call MPI_Allreduce(rc_comm, rc_any, 1, MPI_INTEGER, MPI_MAX, hybrid%par%comm, ierr)
+       if (rc_any /= 0) then     ! every rank leaves RCCL together: the halo goes through tse_f_exchange (MPI) instead
+          call check(tse_comm_abort(ctx), 'tse_comm_abort')
+          if (hybrid%par%rank == 0) write(*,'(a)') ' cuda_mod_hip: WARNING: RCCL communicator could not be initialised; halo exchange over MPI'
+       endif
     endif
     if (ns + nr > 0) then
        allocate(x_slen(max(ns,1),2), x_rlen(max(nr,1),2))
