@@ -60,3 +60,35 @@ def test_remap_q_ppm_single_call(ref_ctx, gold, monkeypatch, generic):
     ref = g["remap_Qout"][which]
     assert np.abs(out - ref).max() <= 5e-13 * np.abs(ref).max(), np.abs(out - ref).max() / np.abs(ref).max()
     np.testing.assert_allclose(out.sum(2), q.sum(2), rtol=1e-13)    # column mass (pin(nlev+1) = pio(nlev+1), :144)
+
+
+def test_remap_segment_tasks_and_generic_loop_leave_the_bits_of_a_whole_sweep(monkeypatch):
+    """k_remap sweeps 32 tracers per round and cuts the remainder (3 of 35) into 8-level segment tasks that start in the middle of
+    a column; elements with a displacement of more than one layer take the generic loop.  All three must produce the same bits
+    for the same column (the column arithmetic spells its fused operations out for that): tracers 33-35 carry copies of
+    tracers 1-3 here, and the whole call is repeated through the generic loop."""
+    from transport_se_amd import cube_mesh as cm
+    from transport_se_amd.hip_mod import HipMod
+    from transport_se_amd.hybvcoord import HvCoord
+    hv = HvCoord()
+    topo = cm.topology(2); geo = cm.geometry(2, topo)
+    d = cm.edge_descriptors(topo, np.zeros(24, int), 0)
+    elem = dict(Dinv=geo["Dinv"], metdet=geo["metdet"], rmetdet=geo["rmetdet"], spheremp=geo["spheremp"], rspheremp=geo["rspheremp"],
+                putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
+    rng = np.random.default_rng(5)
+    dp1 = 1000.0 * (1 + 0.2 * rng.random((24, 72, 4, 4)))
+    dp2 = dp1 * (1 + 0.05 * (rng.random((24, 72, 4, 4)) - 0.5)); dp2 *= dp1.sum(1, keepdims=True) / dp2.sum(1, keepdims=True)
+    for qsize, nseg in ((35, 3), (5, 5), (40, 8)):          # 32 + 3 segments; segments only (two rounds of them); 32 + 8
+        hip = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), qsize, 1e15, device=0)
+        Q = rng.random((24, qsize, 72, 4, 4)) * dp1[:, None]
+        if qsize >= 32:
+            Q[:, qsize - nseg:] = Q[:, :nseg]
+        monkeypatch.setenv("TSE_REMAP_GENERIC", "0")
+        out = hip.remap_q_ppm(Q, dp1, dp2)
+        if qsize >= 32:
+            assert np.array_equal(out[:, qsize - nseg:], out[:, :nseg]), "segment tasks differ from whole sweeps"
+        monkeypatch.setenv("TSE_REMAP_GENERIC", "1")
+        gen = hip.remap_q_ppm(Q, dp1, dp2)
+        assert np.array_equal(out, gen), "generic column loop differs from the lockstep loop (qsize %d)" % qsize
+        np.testing.assert_allclose(out.sum(2), Q.sum(2), rtol=1e-13)
+        hip.close()

@@ -933,9 +933,15 @@ __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0
 // grid coefficients per level -> LDS.  Phase 2: thread = (tracer q, column p) streams down the column keeping a
 // 5-cell window of cell means in registers (kid(k) >= k-1 by construction of the search, :160-166, so the
 // in-place update never overtakes the reads).
-constexpr int REMAP_THREADS = 576;
+constexpr int REMAP_THREADS = 512;   // 8 waves: 2 per SIMD
 constexpr int REMAP_PF = 8;  // column loads kept in flight per thread
 static_assert(REMAP_PF % CL == 0, "a block of REMAP_PF levels holds whole chunks of the bounds layout");
+constexpr int REMAP_SEG_MAX = 8;   // at most this many tracers of an element go through segment tasks (LDS for their mass prefixes)
+// tracers left over after whole rounds of `slots` tracer slots; more than REMAP_SEG_MAX of them take one more (partly idle) round
+__host__ __device__ inline int remap_left(int qsize, int slots, int nt) {
+  const int left = qsize % slots;
+  return nt == 1 && left <= REMAP_SEG_MAX ? left : 0;
+}
 struct RemapLds {
   double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
   double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
@@ -945,30 +951,48 @@ struct RemapLds {
   double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
   int kid[NLEV][16];
   double dA[NLEV], dB[NLEV];       // hyai(k+1)-hyai(k), hybi(k+1)-hybi(k)
+  double mpre[REMAP_SEG_MAX][NLEV / REMAP_PF - 1][16];   // segment tasks: mass of cells 1 .. 8s-1 of the leftover tracers' columns
   int slow;                        // some column has kid(k) outside {k, k+1}
 };
+// The column arithmetic below is compiled WITHOUT implicit FMA contraction and spells its fused operations out: what the
+// compiler fuses on its own depends on which multiplies it happens to see in the same basic block -- in an unrolled block of
+// levels the product a = m/dp of the previous level, across a block boundary not -- so the rounding of a level would depend
+// on where in a block, a sweep or a segment task it is evaluated.  Written out, every level of every column is one fixed
+// sequence of roundings, whatever loop produces it (tests/test_gpu_parity.py: segment tasks against whole sweeps, bit for bit).
+#pragma clang fp contract(off)
 __device__ __forceinline__ double ppm_dma(double d0, double d1, double d2, double am, double a0, double ap) {
-  double da = d0 * (d1 * (ap - a0) + d2 * (a0 - am));
+  double da = d0 * fma(d1, ap - a0, d2 * (a0 - am));
   double m = fmin(fabs(da), fmin(2. * fabs(a0 - am), 2. * fabs(ap - a0)));
   double r = copysign(m, da);
   if ((ap - a0) * (a0 - am) <= 0.) r = 0.;
   return r;
 }
+// interface value between cells j and j+1 (compute_ppm stage 2, :295-303): aj + c3*(ajp-aj) + c4*(c5*(ajp-aj) - c8*dma(j+1) + c9*dma(j))
+__device__ __forceinline__ double ppm_ai(double c3, double c4, double c5, double c8, double c9, double aj, double ajp, double dmajp, double dmaj) {
+  const double d = ajp - aj;
+  return fma(c4, fma(c9, dmaj, fma(c5, d, -(c8 * dmajp))), fma(c3, d, aj));
+}
 __device__ __forceinline__ double remap_dma_at(const RemapLds& S, int j, int p, double am, double a0, double ap) {
   return ppm_dma(S.ppmdx[j][0][p], S.ppmdx[j][1][p], S.ppmdx[j][2][p], am, a0, ap);
 }
 __device__ __forceinline__ double remap_ai_at(const RemapLds& S, int j, int p, double aj, double ajp, double dmajp, double dmaj) {
-  return aj + S.ppmdx[j][3][p] * (ajp - aj) +
-         S.ppmdx[j][4][p] * (S.ppmdx[j][5][p] * (ajp - aj) - S.ppmdx[j][8][p] * dmajp + S.ppmdx[j][9][p] * dmaj);
+  return ppm_ai(S.ppmdx[j][3][p], S.ppmdx[j][4][p], S.ppmdx[j][5][p], S.ppmdx[j][8][p], S.ppmdx[j][9][p], aj, ajp, dmajp, dmaj);
 }
 // limited parabola of one cell from its mean a0 and interface values (compute_ppm stage 3, :309-331)
 __device__ __forceinline__ void remap_coefs(double al, double ar, double a0, double& c0, double& c1, double& c2) {
   if ((ar - a0) * (a0 - al) <= 0.) { al = a0; ar = a0; }
-  if ((ar - al) * (a0 - (al + ar) / 2.) > (ar - al) * (ar - al) * (1.0 / 6.0)) al = 3. * a0 - 2. * ar;
-  if ((ar - al) * (a0 - (al + ar) / 2.) < -((ar - al) * (ar - al)) * (1.0 / 6.0)) ar = 3. * a0 - 2. * al;
-  c0 = 1.5 * a0 - (al + ar) / 4.;
+  if ((ar - al) * fma(-0.5, al + ar, a0) > (ar - al) * (ar - al) * (1.0 / 6.0)) al = fma(3., a0, -2. * ar);
+  if ((ar - al) * fma(-0.5, al + ar, a0) < -((ar - al) * (ar - al)) * (1.0 / 6.0)) ar = fma(3., a0, -2. * al);
+  c0 = fma(1.5, a0, -0.25 * (al + ar));
   c1 = ar - al;
-  c2 = -6. * a0 + 3. * (al + ar);
+  c2 = fma(3., al + ar, -6. * a0);
+}
+// integrate_parabola (:349-356) from x1 = -1/2 to x2: the level-only powers, then the integral
+__device__ __forceinline__ void ppm_zterms(double x2, double& z1, double& zz2, double& z3) {
+  z1 = x2 + 0.5; zz2 = fma(x2, x2, -0.25) * 0.5; z3 = fma(x2 * x2, x2, 0.125);
+}
+__device__ __forceinline__ double ppm_integ(double c0, double c1, double c2, double z1, double zz2, double z3) {
+  return fma(c2 * z3, 1.0 / 3.0, fma(c1, zz2, c0 * z1));
 }
 // Generic column loop (any kid(k) >= k-1): thread = (tracer, column) walks down the column, advancing a 5-cell window by a
 // data-dependent number of cells per level (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209).
@@ -1019,9 +1043,9 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
         ai_m1 = ai_0; ai_0 = remap_ai_at(S, kk, p, a0, ap1, dma_p1, dma_0);
         remap_coefs(ai_m1, ai_0, a0, c0, c1, c2);
       }
-      const double x1 = -0.5, x2 = S.z2[k - 1][p];
-      double integ = c0 * (x2 - x1) + c1 * (x2 * x2 - x1 * x1) * 0.5 + c2 * (x2 * x2 * x2 - x1 * x1 * x1) * (1.0 / 3.0);
-      double massn2 = masso_kk + integ * S.dpo[kk + 1][p];
+      double z1, zz2, z3;
+      ppm_zterms(S.z2[k - 1][p], z1, zz2, z3);
+      double massn2 = fma(ppm_integ(c0, c1, c2, z1, zz2, z3), S.dpo[kk + 1][p], masso_kk);
       const double qnew = massn2 - massn1;
       col[(size_t)(k - 1) * 16] = qnew;
       massn1 = massn2;
@@ -1044,129 +1068,193 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
 // register FIFO with compile-time slots (the level loop is unrolled by REMAP_PF), NT tracers per thread share every LDS
 // read and the level-only part of integrate_parabola.  Arithmetic per value is the same, in the same order, as in the
 // generic loop.
+//
+// Work split (NT = 1).  The loop is bound by VALU issue, so what counts is the number of wave-sweeps on the busiest SIMD.  A
+// block has 8 waves = 32 tracer slots of 16 columns; tracers are swept 32 at a time, and the remainder (3 of 35) is NOT
+// given a ninth wave -- that would put 3 waves on one SIMD and 2 on the others -- but cut into SEGMENTS of REMAP_PF levels
+// that all waves share: a segment task starts from the column's serial mass prefix (k_remap phase 1a left it in LDS, summed
+// in the order of the sweep), primes the 5-cell window from the cells around its first level with the formulas of the
+// sweep, runs the level before its first one with the stores turned into a dump (that yields the running new-grid mass), and
+// then its REMAP_PF levels: the same values in the same order as a whole sweep produces.
 template <int NT>
 __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
                                                    double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink) {
-  const int p = tid & 15;
-  for (int q0 = (tid >> 4) * NT; q0 < qsize; q0 += (nthreads >> 4) * NT) {
-    // The level body below is free of branches and predicated stores, so that the 8 levels of an unrolled block form one
-    // basic block and the scheduler can overlap the dependency chains of neighbouring levels (the kernel waits for memory 9 %
-    // of its time; it is bound by instruction latency at 2.25 waves per SIMD).  A surplus tracer slot (q >= qsize) therefore
-    // reads the last tracer and writes into `sink`; the element min/max is stored by all 16 lanes of the row (same value).
-    double* col[NT];
-    double *colw[NT], *mnp[NT], *mxp[NT];
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-      const bool on = q0 + t < qsize;
-      const int qq = on ? q0 + t : qsize - 1;
-      col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
-      colw[t] = on ? col[t] : sink + p;
-      // bounds of tracer qq at level k: base[(k / CL) * qsize * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
-      mnp[t] = on && mn_out ? mn_out + mm_idx(e, qq, 0, qsize) : sink + NLEV * 16;
-      mxp[t] = on && mn_out ? mx_out + mm_idx(e, qq, 0, qsize) : sink + NLEV * 16 + (size_t)NLEV * qsize;
-    }
-    double pf[NT][REMAP_PF];
-    double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
+  const int p = tid & 15, slots = (nthreads >> 4) * NT;
+  // The level body below is free of branches and predicated stores, so that the 8 levels of an unrolled block form one
+  // basic block and the scheduler can overlap the dependency chains of neighbouring levels.  A surplus tracer slot of the
+  // NT = 2 form (q >= qsize) therefore reads the last tracer and writes into `sink`; the element min/max is stored by all 16
+  // lanes of the row (same value).
+  double* col[NT];
+  double *colw[NT], *mnp[NT], *mxp[NT];
+  double pf[NT][REMAP_PF];
+  double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
+  double* const dump_mn = sink + NLEV * 16;
+  double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * qsize;
+  auto aim = [&](int t, int qq, bool on) __attribute__((always_inline)) {
+    col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
+    colw[t] = on ? col[t] : sink + p;
+    // bounds of tracer qq at level k: base[(k / CL) * qsize * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
+    mnp[t] = on && mn_out ? mn_out + mm_idx(e, qq, 0, qsize) : dump_mn;
+    mxp[t] = on && mn_out ? mx_out + mm_idx(e, qq, 0, qsize) : dump_mx;
+  };
+  // window at the top of the column: a(0) = a(1), a(-1) = a(2)
+  auto prime_top = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       mk[t] = col[t][0]; mk1[t] = col[t][16]; mk2[t] = col[t][32];
 #pragma unroll
       for (int r = 0; r < REMAP_PF; r++) pf[t][r] = col[t][(size_t)(r + 3) * 16];   // cells 4 .. 3+REMAP_PF
     }
-    {
-      const double r1 = S.rdpo[2][p], r2 = S.rdpo[3][p], r3 = S.rdpo[4][p];
+    const double r1 = S.rdpo[2][p], r2 = S.rdpo[3][p], r3 = S.rdpo[4][p];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      ak[t] = mk[t] * r1; ak1[t] = mk1[t] * r2; ak2[t] = mk2[t] * r3;
+      const double dma0 = remap_dma_at(S, 0, p, ak1[t], ak[t], ak[t]);
+      const double dma1 = remap_dma_at(S, 1, p, ak[t], ak[t], ak1[t]);
+      dmak1[t] = remap_dma_at(S, 2, p, ak[t], ak1[t], ak2[t]);
+      aikm1[t] = remap_ai_at(S, 0, p, ak[t], ak[t], dma1, dma0);
+      aik[t] = remap_ai_at(S, 1, p, ak[t], ak1[t], dmak1[t], dma1);
+      masso[t] = 0.0; massn1[t] = 0.0;
+    }
+  };
+  // one level; TAIL: the window may run into the mirrored ghost cells and the FIFO may run dry (the last two blocks of 8, and
+  // every block of a segment task, whose kb differs from lane to lane)
+  const double *bp, *brdpo, *bdpo, *bz2, *bdpn; const int* bkid;   // per-block LDS bases
+  auto bases = [&](int kb) __attribute__((always_inline)) {
+    bp = &S.ppmdx[kb][0][p]; brdpo = &S.rdpo[kb][p]; bdpo = &S.dpo[kb][p]; bz2 = &S.z2[kb][p]; bdpn = &S.dpn[kb][p]; bkid = &S.kid[kb][p];
+  };
+  auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl, auto reload_tag) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value, RELOAD = decltype(reload_tag)::value;   // RELOAD: keep the FIFO filled
+    const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
+    double ak3[NT], mk3[NT];
+    if (!TAIL || r <= NLEV) {
+      const double rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1]
 #pragma unroll
       for (int t = 0; t < NT; t++) {
-        ak[t] = mk[t] * r1; ak1[t] = mk1[t] * r2; ak2[t] = mk2[t] * r3;
-        // a(0) = a(1), a(-1) = a(2)
-        const double dma0 = remap_dma_at(S, 0, p, ak1[t], ak[t], ak[t]);
-        const double dma1 = remap_dma_at(S, 1, p, ak[t], ak[t], ak1[t]);
-        dmak1[t] = remap_dma_at(S, 2, p, ak[t], ak1[t], ak2[t]);
-        aikm1[t] = remap_ai_at(S, 0, p, ak[t], ak[t], dma1, dma0);
-        aik[t] = remap_ai_at(S, 1, p, ak[t], ak1[t], dmak1[t], dma1);
-        masso[t] = 0.0; massn1[t] = 0.0;
+        mk3[t] = pf[t][sl];
+        if (RELOAD && (!TAIL || r + REMAP_PF <= NLEV)) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
+        ak3[t] = mk3[t] * rr;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NT; t++) {   // a(nlev+1) = a(nlev), a(nlev+2) = a(nlev-1); nothing beyond is used
+        mk3[t] = 0.0;
+        ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
       }
     }
-    // one level; TAIL: the last two blocks of 8, where the window runs into the mirrored ghost cells and the FIFO runs dry
-    const double *bp, *brdpo, *bdpo, *bz2, *bdpn; const int* bkid;   // per-block LDS bases
-    auto bases = [&](int kb) __attribute__((always_inline)) {
-      bp = &S.ppmdx[kb][0][p]; brdpo = &S.rdpo[kb][p]; bdpo = &S.dpo[kb][p]; bz2 = &S.z2[kb][p]; bdpn = &S.dpn[kb][p]; bkid = &S.kid[kb][p];
-    };
-    auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl) __attribute__((always_inline)) {
-      constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value;
-      const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
-      double ak3[NT], mk3[NT];
-      if (!TAIL || r <= NLEV) {
-        const double rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1]
+    // LDS reads relative to per-block bases (bp = &ppmdx[kb][0][p] etc., set up once per 8 levels): the offsets are then
+    // small compile-time immediates.  Indexed from the struct base, most of the 147 KB lie beyond the 64 KB an LDS
+    // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
+    const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
+    const double d0 = bp[(jdo * 10 + 0) * 16], d1 = bp[(jdo * 10 + 1) * 16], d2 = bp[(jdo * 10 + 2) * 16];
+    const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e567 = bp[(jao * 10 + 5) * 16],
+                 e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
+    const int kt = bkid[sl * 16];
+    const bool o = kt != k;   // kid(k) == k+1
+    const double dsel = o ? bdpo[(sl + 3) * 16] : bdpo[(sl + 2) * 16], dn = bdpn[sl * 16];
+    double z1, zz2, z3;
+    ppm_zterms(bz2[sl * 16], z1, zz2, z3);
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-          mk3[t] = pf[t][sl];
-          if (!TAIL || r + REMAP_PF <= NLEV) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
-          ak3[t] = mk3[t] * rr;
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; t++) {   // a(nlev+1) = a(nlev), a(nlev+2) = a(nlev-1); nothing beyond is used
-          mk3[t] = 0.0;
-          ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
-        }
+    for (int t = 0; t < NT; t++) {
+      const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
+      const double aik1 = ppm_ai(e3, e4, e567, e8, e9, ak1[t], ak2[t], dmak2, dmak1[t]);
+      const double mo1 = masso[t] + mk[t];
+      const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
+      double c0, c1, c2;
+      remap_coefs(al, ar, a0, c0, c1, c2);
+      const double massn2 = fma(ppm_integ(c0, c1, c2, z1, zz2, z3), dsel, ms);
+      const double qnew = massn2 - massn1[t];
+      colw[t][(size_t)(k - 1) * 16] = qnew;
+      massn1[t] = massn2;
+      if (EMIT) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
+        const double x = qnew * dn;
+        double mn = x, mx = x;
+        mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
+        mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
+        const size_t mo = (size_t)((kb + sl) / CL) * qsize * CL + (sl % CL);   // kb is a multiple of 8
+        mnp[t][mo] = mn; mxp[t][mo] = mx;   // every lane of the row holds the row's result
       }
-      // LDS reads relative to per-block bases (bp = &ppmdx[kb][0][p] etc., set up once per 8 levels): the offsets are then
-      // small compile-time immediates.  Indexed from the struct base, most of the 147 KB lie beyond the 64 KB an LDS
-      // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
-      const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
-      const double d0 = bp[(jdo * 10 + 0) * 16], d1 = bp[(jdo * 10 + 1) * 16], d2 = bp[(jdo * 10 + 2) * 16];
-      const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e567 = bp[(jao * 10 + 5) * 16],
-                   e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
-      const int kt = bkid[sl * 16];
-      const bool o = kt != k;   // kid(k) == k+1
-      const double x1 = -0.5, x2 = bz2[sl * 16], dsel = o ? bdpo[(sl + 3) * 16] : bdpo[(sl + 2) * 16], dn = bdpn[sl * 16];
-      const double z1 = x2 - x1, zz2 = (x2 * x2 - x1 * x1) * 0.5, z3 = x2 * x2 * x2 - x1 * x1 * x1;
+      masso[t] = mo1;
+      ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
+      mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
+      dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
+    }
+  };
+  // scheduler fence every 4 levels (fences every 2 or 8 levels: same time; 244 instead of 212 registers without)
+  auto block = [&](auto tail_tag, auto emit_tag, int kb, auto reload_tag) __attribute__((always_inline)) {
+    bases(kb);
 #pragma unroll
-      for (int t = 0; t < NT; t++) {
-        const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
-        const double aik1 = ak1[t] + e3 * (ak2[t] - ak1[t]) + e4 * (e567 * (ak2[t] - ak1[t]) - e8 * dmak2 + e9 * dmak1[t]);
-        const double mo1 = masso[t] + mk[t];
-        const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
-        double c0, c1, c2;
-        remap_coefs(al, ar, a0, c0, c1, c2);
-        const double integ = c0 * z1 + c1 * zz2 + c2 * z3 * (1.0 / 3.0);
-        const double massn2 = ms + integ * dsel;
-        const double qnew = massn2 - massn1[t];
-        colw[t][(size_t)(k - 1) * 16] = qnew;
-        massn1[t] = massn2;
-        if (EMIT) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-          const double x = qnew * dn;
-          double mn = x, mx = x;
-          mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
-          mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-          const size_t mo = (size_t)((kb + sl) / CL) * qsize * CL + (sl % CL);   // kb is a multiple of 8
-          mnp[t][mo] = mn; mxp[t][mo] = mx;   // every lane of the row holds the row's result
-        }
-        masso[t] = mo1;
-        ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
-        mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
-        dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
-      }
-    };
-    auto column = [&](auto emit_tag) __attribute__((always_inline)) {
-      constexpr int CLEAN = NLEV - 2 * REMAP_PF;   // blocks starting below this never see a ghost cell or an empty FIFO slot
-      // scheduler fence every 4 levels: an unfenced block of 8 overlaps so much that 35 registers spill (168 is the cap at 9 waves)
-      for (int kb = 0; kb < CLEAN; kb += REMAP_PF) {
-        bases(kb);
+    for (int sl = 0; sl < REMAP_PF; sl++) { level(tail_tag, emit_tag, kb, sl, reload_tag); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+  };
+  constexpr int CLEAN = NLEV - 2 * REMAP_PF;   // blocks starting below this never see a ghost cell or an empty FIFO slot
+  auto column = [&](auto emit_tag) __attribute__((always_inline)) {
+    for (int kb = 0; kb < CLEAN; kb += REMAP_PF) block(std::false_type{}, emit_tag, kb, std::true_type{});
+    for (int kb = CLEAN; kb < NLEV; kb += REMAP_PF) block(std::true_type{}, emit_tag, kb, std::true_type{});
+  };
+
+  // ---- whole sweeps, `slots` tracers at a time
+  const int left = remap_left(qsize, slots, NT);          // tracers that go through segment tasks instead
+  const int qsweep = qsize - left;
+  for (int q0 = (tid >> 4) * NT; q0 < qsweep; q0 += slots) {
 #pragma unroll
-        for (int sl = 0; sl < REMAP_PF; sl++) { level(std::false_type{}, emit_tag, kb, sl); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
-      }
-      for (int kb = CLEAN; kb < NLEV; kb += REMAP_PF) {
-        bases(kb);
-#pragma unroll
-        for (int sl = 0; sl < REMAP_PF; sl++) { level(std::true_type{}, emit_tag, kb, sl); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
-      }
-    };
+    for (int t = 0; t < NT; t++) { const bool on = q0 + t < qsize; aim(t, on ? q0 + t : qsize - 1, on); }
+    prime_top();
     if (mn_out) column(std::true_type{});
     else column(std::false_type{});
   }
+  // ---- the remaining tracers as segment tasks: (tracer, segment) pairs, 16 columns each, dealt to the tracer slots -- the
+  //      segments that start inside the column first, the top segments (plain start) last, so that a wave holds one kind.
+  //      The column is updated in place: a task's window reaches into its neighbours' levels, so all tasks of a tracer run in
+  //      the same round, and a workgroup barrier separates the loads of a round (everything a task reads is in registers
+  //      after its run-in level) from its stores.
+  if constexpr (NT == 1) {
+    constexpr int NSEG = NLEV / REMAP_PF;
+    const int per = slots / NSEG;                                  // tracers per round
+    for (int tb = 0; tb < left; tb += per) {                       // (uniform over the block)
+      const int ntr = min(per, left - tb), nwarm = ntr * (NSEG - 1), g = tid >> 4;
+      const bool act = g < ntr * NSEG, warm = g < nwarm;
+      const int tr = warm ? g / (NSEG - 1) : g - nwarm, kb0 = warm ? (g - tr * (NSEG - 1) + 1) * REMAP_PF : 0;
+      if (act) {
+        aim(0, qsweep + tb + tr, true);
+        if (warm) {
+          // state on entry of level kb0 (the one before the segment): cells kb0-2 .. kb0+2 (cell j = col[(j-1)*16], a = m*rdpo[j+1])
+          const double* c = col[0] + (size_t)(kb0 - 3) * 16;
+          const double m_2 = c[0], m_1 = c[16];
+          mk[0] = c[32]; mk1[0] = c[48]; mk2[0] = c[64];
+          pf[0][REMAP_PF - 1] = c[80];                                              // cell kb0+3, consumed by the run-in level
+#pragma unroll
+          for (int r = 0; r + 1 < REMAP_PF; r++) pf[0][r] = kb0 + r + 4 <= NLEV ? c[(size_t)(r + 6) * 16] : 0.0;   // cells kb0+4 .. kb0+10
+          const double* rd = &S.rdpo[kb0 - 1][p];
+          const double a_2 = m_2 * rd[0], a_1 = m_1 * rd[16];
+          ak[0] = mk[0] * rd[32]; ak1[0] = mk1[0] * rd[48]; ak2[0] = mk2[0] * rd[64];
+          const double dma_1 = remap_dma_at(S, kb0 - 1, p, a_2, a_1, ak[0]);
+          const double dma0 = remap_dma_at(S, kb0, p, a_1, ak[0], ak1[0]);
+          dmak1[0] = remap_dma_at(S, kb0 + 1, p, ak[0], ak1[0], ak2[0]);
+          aikm1[0] = remap_ai_at(S, kb0 - 1, p, a_1, ak[0], dma0, dma_1);
+          aik[0] = remap_ai_at(S, kb0, p, ak[0], ak1[0], dmak1[0], dma0);
+          masso[0] = S.mpre[tb + tr][kb0 / REMAP_PF - 1][p];                         // sum of cells 1 .. kb0-1 in sweep order
+          massn1[0] = 0.0;
+          // run-in: level kb0 itself (slot REMAP_PF-1 of the block before), results dumped; it also fetches cell kb0+11
+          double* const w = colw[0]; double* const a = mnp[0]; double* const b = mxp[0];
+          colw[0] = sink + p; mnp[0] = dump_mn; mxp[0] = dump_mx;
+          bases(kb0 - REMAP_PF);
+          if (mn_out) level(std::true_type{}, std::true_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
+          else level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
+          colw[0] = w; mnp[0] = a; mxp[0] = b;
+        } else {
+          prime_top();
+        }
+      }
+      __syncthreads();   // (waits for the loads, too)
+      if (act) {
+        if (mn_out) block(std::true_type{}, std::true_type{}, kb0, std::false_type{});
+        else block(std::true_type{}, std::false_type{}, kb0, std::false_type{});
+      }
+    }
+  }
 }
+
+#pragma clang fp contract(fast)   // (the default of the rest of the file)
 
 template <int NT>
 __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
@@ -1234,6 +1322,22 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
         pin = pin + d[i];
         S.z2[k - 1][p] = (k == NLEV) ? pio_prev : pin;  // pin(nlev+1) = pio(nlev+1)
       }
+    }
+  } else if (tid >= 64 && tid < 64 + 16 * remap_left(qsize, (nthreads >> 4) * NT, NT)) {
+    // meanwhile the second wave sums the old masses of the tracers that phase 2 handles as segment tasks: sum of cells
+    // 1 .. 8s-1 for s = 1..8, added from 0 in the order of the sweep (masso in remap_columns_fast)
+    const int left = remap_left(qsize, (nthreads >> 4) * NT, NT), tr = (tid - 64) >> 4, p = tid & 15;
+    const double* c = Q + ((size_t)e * qsize + (qsize - left + tr)) * NLEV * 16 + p;
+    // all loads first (one memory round trip; the registers are free in this phase), then the serial adds
+    constexpr int NPRE = NLEV - REMAP_PF;
+    double m[NPRE];
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) m[i] = c[(size_t)i * 16];
+    double run = 0.0;
+#pragma unroll
+    for (int i = 0; i < NPRE; i++) {
+      if (i % REMAP_PF == REMAP_PF - 1) S.mpre[tr][i / REMAP_PF][p] = run;   // before cell 8s is added: cells 1 .. 8s-1
+      run = run + m[i];
     }
   }
   __syncthreads();
