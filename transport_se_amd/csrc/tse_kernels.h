@@ -1088,6 +1088,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   double *colw[NT], *mnp[NT], *mxp[NT];
   double pf[NT][REMAP_PF];
   double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
+  double xq[NT][CL];   // Q of the levels of the current chunk (fused bounds emission)
   double* const dump_mn = sink + NLEV * 16;
   double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * qsize;
   auto aim = [&](int t, int qq, bool on) __attribute__((always_inline)) {
@@ -1166,25 +1167,41 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       const double qnew = massn2 - massn1[t];
       colw[t][(size_t)(k - 1) * 16] = qnew;
       massn1[t] = massn2;
-      if (EMIT) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-        const double x = qnew * dn;
-        double mn = x, mx = x;
-        mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
-        mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-        const size_t mo = (size_t)((kb + sl) / CL) * qsize * CL + (sl % CL);   // kb is a multiple of 8
-        mnp[t][mo] = mn; mxp[t][mo] = mx;   // every lane of the row holds the row's result
-      }
+      if (EMIT) xq[t][sl % CL] = qnew * dn;   // Q = Qdp/dp of the next step's stage 1; reduced over the columns by emit4
       masso[t] = mo1;
       ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
       mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
       dmak1[t] = dmak2; aikm1[t] = aik[t]; aik[t] = aik1;
     }
   };
+  // Element min/max of Q over the 16 columns (one DPP row) for the 4 levels of a chunk at once, as a halving butterfly: lane
+  // pairs (xor 1) split the 4 levels between them -- each keeps two and hands the other two over, the moves shared by min and
+  // max --, lane pairs (xor 2) split again, and two row rotations finish across the quads: 42 instead of 96 DPP moves and
+  // min/max per chunk, and the lane that ends up with level 2*(p&1) + ((p>>1)&1) of the chunk stores it (4 lanes: one line).
+  auto emit4 = [&](int kb, int sl0) __attribute__((always_inline)) {
+    const bool b0 = p & 1, b1 = p & 2;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+      const double* x = xq[t];
+      const double s0 = b0 ? x[0] : x[2], s1 = b0 ? x[1] : x[3], k0 = b0 ? x[2] : x[0], k1 = b0 ? x[3] : x[1];
+      const double r0 = dppq<0xB1>(s0), r1 = dppq<0xB1>(s1);
+      const double n0 = fmin(k0, r0), n1 = fmin(k1, r1), m0 = fmax(k0, r0), m1 = fmax(k1, r1);
+      double mn = fmin(b1 ? n1 : n0, dppq<0x4E>(b1 ? n0 : n1));
+      double mx = fmax(b1 ? m1 : m0, dppq<0x4E>(b1 ? m0 : m1));
+      mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
+      mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
+      const size_t mo = (size_t)((kb + sl0) / CL) * qsize * CL + (b0 ? 2 : 0) + (b1 ? 1 : 0);   // kb, sl0 are multiples of CL
+      mnp[t][mo] = mn; mxp[t][mo] = mx;   // (the four quads of the row hold and store the same four values)
+    }
+  };
   // scheduler fence every 4 levels (fences every 2 or 8 levels: same time; 244 instead of 212 registers without)
   auto block = [&](auto tail_tag, auto emit_tag, int kb, auto reload_tag) __attribute__((always_inline)) {
     bases(kb);
 #pragma unroll
-    for (int sl = 0; sl < REMAP_PF; sl++) { level(tail_tag, emit_tag, kb, sl, reload_tag); if (sl % 4 == 3) __builtin_amdgcn_sched_barrier(0); }
+    for (int sl = 0; sl < REMAP_PF; sl++) {
+      level(tail_tag, emit_tag, kb, sl, reload_tag);
+      if (sl % CL == CL - 1) { if (decltype(emit_tag)::value) emit4(kb, sl - (CL - 1)); __builtin_amdgcn_sched_barrier(0); }
+    }
   };
   constexpr int CLEAN = NLEV - 2 * REMAP_PF;   // blocks starting below this never see a ghost cell or an empty FIFO slot
   auto column = [&](auto emit_tag) __attribute__((always_inline)) {
@@ -1234,13 +1251,12 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
           aik[0] = remap_ai_at(S, kb0, p, ak[0], ak1[0], dmak1[0], dma0);
           masso[0] = S.mpre[tb + tr][kb0 / REMAP_PF - 1][p];                         // sum of cells 1 .. kb0-1 in sweep order
           massn1[0] = 0.0;
-          // run-in: level kb0 itself (slot REMAP_PF-1 of the block before), results dumped; it also fetches cell kb0+11
-          double* const w = colw[0]; double* const a = mnp[0]; double* const b = mxp[0];
-          colw[0] = sink + p; mnp[0] = dump_mn; mxp[0] = dump_mx;
+          // run-in: level kb0 itself (slot REMAP_PF-1 of the block before), its value dumped; it also fetches cell kb0+11
+          double* const w = colw[0];
+          colw[0] = sink + p;
           bases(kb0 - REMAP_PF);
-          if (mn_out) level(std::true_type{}, std::true_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
-          else level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
-          colw[0] = w; mnp[0] = a; mxp[0] = b;
+          level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
+          colw[0] = w;
         } else {
           prime_top();
         }
