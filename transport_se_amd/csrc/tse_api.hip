@@ -91,7 +91,7 @@ struct tse_ctx {
   struct Pending { const char* name; hipEvent_t a, b; };
   std::vector<Pending> pending;       // event pairs recorded on `stream`, resolved lazily (no sync inside the step)
   std::vector<hipEvent_t> free_events;
-  double *sink = nullptr;   // write-only dump of the remap's surplus tracer slots: 16 columns x 72 levels, then two bounds areas
+  double *sink = nullptr;   // write-only dump of k_remap (run-in levels of its segment tasks, surplus tracer slots): 16 columns x 72 levels, then two bounds areas
   double *eta2 = nullptr;   // with lvl_tmp: twin buffers of the level fields (k_dss_lvl writes out of place, then swap)
   bool t_zero_dirty = false;   // the per-stage stage-3 path used T as a plain [e][q][k][p] field (overwrites its zero elements)
   size_t tps = 0;   // plane stride (doubles) of the scratch fields T and B: NCHUNK chunks of (slots, a zero slot, the halo columns)
@@ -849,8 +849,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     c->t_zero_dirty = true;   // below, T receives rspheremp*DSS(lap) in the plain tracer layout
     {
       Scope s(c, "lap");
-      hipLaunchKernelGGL(k_lap1<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax,
-                         (double*)nullptr, plain);
+      hipLaunchKernelGGL(k_lap1<0>, grid, blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dt, Qn0, c->B, c->dp, c->divdp_proj, c->qmin, c->qmax, plain);
       LAUNCH_CHECK();
     }
     // biharmonic_wk_scalar_minmax: DSS(lap1) (+ min/max exchange) -> T = rspheremp*DSS(lap1).  The reference's message is
@@ -1006,7 +1005,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
-                             c->divdp_proj, c->qmin, c->qmax, (double*)nullptr, gargs(w, nullptr, 0, c->eta, NLEVP));
+                             c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
                               unpack_halo(c, cs, c->T, nq); })) return 1;

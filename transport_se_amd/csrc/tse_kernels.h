@@ -428,8 +428,8 @@ __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 // GIN: DSS on read (whole-step path; block = patch x chunk, see above).  1: the tracer input is rspheremp*DSS of the previous
-// stage's pre-DSS scratch (passed in Qn0, scratch layout); 2: the Laplacian input `lap` is (RHS == 2 only); 3: both -- stage 3
-// then never needs the DSS'd stage-2 tracers in memory (k_lap1 does not store them).
+// stage's pre-DSS scratch (passed in Qn0, scratch layout); 3: so is the Laplacian input `lap` (RHS == 2) -- stage 3 then never
+// needs the DSS'd stage-2 tracers in memory (k_lap1 does not store them).
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
@@ -439,6 +439,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
+  static_assert(GIN == 0 || GIN == 1 || (GIN == 3 && RHS == 2), "plain inputs, gathered tracers, or gathered tracers and Laplacian");
   __shared__ PatchLds lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
@@ -519,13 +520,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   };
   GatherRaw graw, graw2;                                 // raw own / ring loads of the gathered input(s) (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
-  const double* gsrc = GIN == 2 ? lap : Qn0;             // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
   auto fetch = [&](int q) {   // loads only
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = mm_idx(e, q, kc, qsize);
-    if (GIN) gather_issue(RG, GA, gsrc, q, graw);
+    if (GIN) gather_issue(RG, GA, Qn0, q, graw);              // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
     if (GIN == 3) gather_issue(RG, GA, lap, q, graw2);
-    if (GIN == 0 || GIN == 2) load4(Qn0 + so, qnx);
-    if (RHS == 2 && GIN < 2) load4(lap + so, lsx);
+    if (GIN == 0) load4(Qn0 + so, qnx);
+    if (RHS == 2 && GIN != 3) load4(lap + so, lsx);
     minx = qmin[mi]; maxx = qmax[mi];
   };
   if (GIN == 3 && threadIdx.x < 2 * CL) lds_[GIN == 3 ? 1 : 0].v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;
@@ -536,12 +536,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     double qn[4], ls[4] = {0, 0, 0, 0}, own[4], own2[4], minp = minx, maxp = maxx;
     if (GIN) gather_publish(RG, lds_[0], q & 1, kc, graw, own);
     if (GIN == 3) gather_publish(RG, lds_[GIN == 3 ? 1 : 0], q & 1, kc, graw2, own2);
-    if (GIN == 0 || GIN == 2) {
+    if (GIN == 0) {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
       asm volatile("" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : : "memory");   // the wait belongs here, not below
     }
-    if (RHS >= 2 && GIN < 2) {
+    if (RHS == 2 && GIN != 3) {
 #pragma unroll
       for (int i = 0; i < 4; i++) ls[i] = lsx[i];
       asm volatile("" : "+v"(ls[0]), "+v"(ls[1]), "+v"(ls[2]), "+v"(ls[3]) : : "memory");
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     __builtin_amdgcn_sched_barrier(0);
     if (GIN) {
       lds_barrier();
-      gather_sum(RG, lds_[0], q & 1, j, own, GIN == 2 ? ls : qn);
+      gather_sum(RG, lds_[0], q & 1, j, own, qn);
       if (GIN == 3) gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
     }
     double bih[4] = {0, 0, 0, 0};
@@ -624,13 +624,12 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // stage-3 prologue (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389):
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
 // GIN == 1 (whole-step path; block = patch x chunk): Qn0 is the stage-2 pre-DSS scratch; the DSS'd Qdp is assembled on read
-// and, if Qout is given, also stored there (the default k_advance<2,3> of stage 3 assembles it again itself instead).
+// and not stored (k_advance<2,3> of stage 3 assembles it again itself).
 template <int GIN = 0>
 __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
-                                                       double* __restrict__ qmin, double* __restrict__ qmax, double* __restrict__ Qout,
-                                                       GatherArgs GA) {
+                                                       double* __restrict__ qmin, double* __restrict__ qmax, GatherArgs GA) {
   __shared__ PatchLds lds_;
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
@@ -688,9 +687,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   //   loads -> workgroup barrier -> neighbour values from LDS, sum -> compute.
   // The results go to a second register set (A/B alternate), so that the stores issued at the top of a step drain during
   // the whole step and nothing waits for them.
-  struct Out { double q[4], l[4], mn, mx; };
+  struct Out { double l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
-    if (Qout && k < NLEV) store4(Qout + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.q);
     store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.l);
     if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = o.mn; qmax[mm_idx(e, q, k, qsize)] = o.mx; }
   };
@@ -704,7 +702,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
     lds_barrier();
     gather_sum(RG, lds_, q & 1, j, own, x);
 #pragma unroll
-    for (int i = 0; i < 4; i++) { cur.q[i] = x[i]; x[i] = x[i] * dpk[i]; }
+    for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
     cur.mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     cur.mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     laplace_lean_row(D, L, x, cur.l);
