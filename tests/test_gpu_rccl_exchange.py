@@ -178,3 +178,18 @@ def test_ranks_that_cannot_build_a_communicator_fall_back_together(tmp_path):
     assert res["comm"] == [0, 1]                      # no communicator left behind
     assert b"WARNING: RCCL communicator" in r.stderr
     assert res["checksum"] == ref
+
+
+def test_rank_rehearsal_tool_runs_one_rank_of_a_partition_in_loopback():
+    """tools/rank_rehearsal.py (DESIGN section 4's per-rank timings): rank 1 of a 4-rank partition of ne8, alone, RCCL in loopback"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rank_rehearsal.py"), "--ne", "8", "--qsize", "4", "--world", "4", "--rank", "1",
+                        "--cycles", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["world"] == 4 and d["rank"] == 1 and d["elements"] == 96 and 0 < d["boundary_elements"] < 96
+    assert d["neighbour_ranks"] >= 1 and d["send_columns"] > 0 and d["ms_per_step"] > 0
+    assert all(d["kernel_ms_per_step_timing_mode"][k] > 0 for k in ("advance0", "advance1", "advance2", "lap", "dss", "remap"))

@@ -54,7 +54,7 @@ def main():
         h.timing(True)
         n = h.prim_run_subcycle(tstep, 1, n)
         h.synchronize()
-        kt = {k: round(h.kernel_time(k)[0] / 3, 3) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap", "level", "dcmip", "halo", "pack")}
+        kt = {k: round(h.kernel_time(k)[0] / 3, 3) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap", "level", "dcmip")}
         h.timing(False)
         nb, ni = h.boundary_layout()
         ncol = sum(s[2] for s in d["send"])
