@@ -54,6 +54,7 @@ struct tse_ctx {
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
   int* bad = nullptr;
+  int* pering = nullptr; unsigned char* pnb = nullptr;   // element ring / neighbour entries of the patches (stage-3 bounds)
   int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
   int mm_halo = 0;    // == mm_valid: the neighbour ranks' share of those bounds is already in recvbuf_mm (or on its way: ev_mm)
   hipEvent_t ev_mm = nullptr;   // completion of that prefetched exchange on the communication stream
@@ -100,7 +101,7 @@ struct tse_ctx {
   unsigned halo0() const { return (unsigned)(nslots + 1) * 16; }    // entry index of halo column 0
   GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
                    double* var_out = nullptr, int var_out_lev = 0) const {
-    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev};
+    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, pering, pnb};
   }
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
@@ -344,6 +345,17 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
       std::sort(refs.begin(), refs.end());
       return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
     };
+    auto ering_size = [&](const std::vector<int>& cand, int me) {   // distinct elements (local or received) around the candidate
+      std::vector<long> refs;
+      for (int e : cand)
+        for (int d = 0; d < 8; d++) {
+          const int nb = nbr[e * 8 + d];
+          if (nb == -1 || (nb >= 0 && pid[nb] == me)) continue;
+          refs.push_back(nb);
+        }
+      std::sort(refs.begin(), refs.end());
+      return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
+    };
     for (int seed = 0; seed < n; seed++) {
       if (pid[seed] >= 0) continue;
       const int me = (int)patches.size();
@@ -356,7 +368,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
           while (e >= 0 && pid[e] < 0 && cnt < 4) { pid[e] = me; cand.push_back(e); cnt++; e = nbr[e * 8 + 1]; }   // east
           rowstart = nbr[first * 8 + 3];                                                                         // north
         }
-        if (ring_size(cand, me) <= NRMAX || maxrows == 1) { patches.push_back(cand); break; }
+        if ((ring_size(cand, me) <= NRMAX && ering_size(cand, me) <= NER) || maxrows == 1) { patches.push_back(cand); break; }
         for (int e : cand) pid[e] = -1;   // too long a halo ring for one load per lane: fewer rows
       }
     }
@@ -389,6 +401,29 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
         }
       }
     }
+    // element ring and neighbour entries of every patch, for the bounds image of the stage-3 kernel (k_advance<2,3>)
+    std::vector<int> pering((size_t)c->npatch * NER, 0);
+    std::vector<unsigned char> pnb((size_t)c->nslots * 8, 255);
+    for (int pi = 0; pi < c->npatch; pi++) {
+      std::map<int, int> ring;   // element (or -(received entry) - 2) -> ring entry
+      for (int r = 0; r < NER; r++) pering[(size_t)pi * NER + r] = patches[pi][0];   // unused entries: any valid element
+      for (size_t i = 0; i < patches[pi].size(); i++) {
+        const int e = patches[pi][i];
+        for (int d = 0; d < 8; d++) {
+          const int nb = nbr[e * 8 + d];
+          if (nb == -1) continue;
+          if (nb >= 0 && pid[nb] == pi) { pnb[((size_t)pi * PS + i) * 8 + d] = (unsigned char)(slot_of[nb] - pi * PS); continue; }
+          auto it = ring.find(nb);
+          if (it == ring.end()) {
+            if ((int)ring.size() >= NER) return fail("tse_init: patch %d has more than %d elements around it", pi, NER);
+            it = ring.emplace(nb, (int)ring.size()).first;
+            pering[(size_t)pi * NER + it->second] = nb >= 0 ? nb : n + (-(nb + 2));
+          }
+          pnb[((size_t)pi * PS + i) * 8 + d] = (unsigned char)(PS + it->second);
+        }
+      }
+    }
+    if (upload(&c->pering, pering) || upload(&c->pnb, pnb)) return 1;
     std::vector<int2> send_s(send_src);
     for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(t.y); }   // {slot, position within the slot}
     // rank-boundary patches first, as the elements above
@@ -422,7 +457,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
       dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)NLEV * c->qsize) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
-  const size_t mm = (size_t)n * c->qsize * NLEV;
+  // (behind the local elements: room for the received bounds of the compact exchange, see k_unpack_minmax)
+  const size_t mm = (size_t)(n + c->nmm_recv) * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
   HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
   HIPCHK(hipMemset(c->vn0, 0, 2 * lev * 8)); HIPCHK(hipMemset(c->dp, 0, lev * 8)); HIPCHK(hipMemset(c->divdp, 0, lev * 8));
@@ -479,7 +515,7 @@ void tse_finalize(tse_ctx* c) {
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
                   c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->pslots, c->plist_bnd,
-                  c->plist_int, c->pring, c->plds, c->send_src_s};
+                  c->plist_int, c->pring, c->plds, c->send_src_s, c->pering, c->pnb};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   resolve_timers(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
@@ -760,6 +796,18 @@ static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo,
   return 0;
 }
 
+// received element bounds -> behind the local elements of qmin/qmax (read by the stage-3 kernel through its element ring)
+static int unpack_minmax(tse_ctx* c, hipStream_t st) {
+  const int m = c->qsize * NLEV;
+  if (!c->nmm_recv) return 0;
+  unsigned nb;
+  if (halo_items((size_t)c->nmm_recv * (m / 2), &nb)) return 1;
+  hipLaunchKernelGGL(k_unpack_minmax, dim3(nb), dim3(256), 0, st, c->nmm_recv, m, (const double*)c->recvbuf_mm, c->qmin + (size_t)c->nelemd * m,
+                     c->qmax + (size_t)c->nelemd * m);
+  LAUNCH_CHECK();
+  return 0;
+}
+
 // min/max over the <= 8 neighbours of qmin/qmax (double-buffered on the device); the halo part must have arrived
 static int nbr_minmax_kernel(tse_ctx* c) {
   const int m = c->qsize * NLEV;
@@ -1000,16 +1048,16 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
 
   // ---- stage 3 (rhs_multiplier 2, DSS extra = omega_p)
   // 3a: B (+) edges -> first Laplacian (pre-DSS) of the stage-2 tracers in T, element min/max (the DSS'd tracers themselves are
-  //     not stored: 3b assembles them again from B); the bounds and the Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
+  //     not stored: 3b assembles them again from B); the element bounds and the Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
   if (split_stage(c, "lap",
         [&](Work w) -> int {
           if (!w.npwork) return 0;
           hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
                              c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || pack_tracers(c, cs, c->T, nq) || halo_exchange(c, nq, 0, cs) ||
-                              unpack_halo(c, cs, c->T, nq); })) return 1;
-  if (nbr_minmax_kernel(c)) return 1;
+        [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || unpack_minmax(c, cs) || pack_tracers(c, cs, c->T, nq) ||
+                              halo_exchange(c, nq, 0, cs) || unpack_halo(c, cs, c->T, nq); })) return 1;
+  // (no neighbour min/max pass here: 3b forms it from the element bounds -- its patch's and the element ring's -- while it runs)
   // 3b: B (+) edges, T (+) edges -> C (2nd Laplacian + biharmonic scaling + advance + limiter)
   if (split_stage(c, "advance2",
         [&](Work w) -> int {

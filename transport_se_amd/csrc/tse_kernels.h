@@ -250,6 +250,9 @@ __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qs
 // plist/npwork: the patches this launch walks (nullptr: patches 0..npwork).  A multi-rank step launches every slab kernel
 // twice: first over the patches (plain kernels: elements, order/nwork) that touch another rank, so that their halo can travel
 // while the second launch computes the interior (tse_api.hip).
+constexpr int NER = 32;            // elements around a patch whose bounds the stage-3 kernel reads (a full 4x4 patch has 20)
+constexpr int BND_ENT = PS + NER;  // element entries of its bounds image in LDS: the patch's slots, then the element ring
+static_assert(BND_ENT * 4 <= FLAT_THREADS, "one 16-byte load per lane fills the bounds image");
 struct GatherArgs {
   Scr S;
   const int* slot_of;              // element -> slot of the scratch layout
@@ -263,7 +266,11 @@ struct GatherArgs {
   // one more plane (index qsize) of the scratch fields, exactly as edgeAdv_p1 carries it behind the tracers:
   const double* var_in;  int var_in_lev;    // producer: plane qsize of the output := spheremp * var_in[e][var_in_lev][p] (levels 0..71)
   double* var_out;       int var_out_lev;   // consumer: rspheremp*DSS(plane qsize of the gathered input) -> var_out[e][var_out_lev][p]
+  // stage 3 forms the neighbour min/max of the element bounds itself (min/max half of biharmonic_wk_scalar_minmax):
+  const int* pering;               // [npatch][NER] elements around the patch (>= nelemd: received entry nelemd + i, stored behind the local elements)
+  const unsigned char* pnb;        // [npatch][PS][8] neighbour d of a slot -> entry of the bounds image (slot, PS + ring entry, 255 = none)
 };
+struct BoundsLds { double v[2][BND_ENT][2][CL]; };   // [buffer][element entry][min|max][level of the chunk]: 6 KB
 constexpr int LDS_ZERO = PS * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
 struct PatchLds { double v[2][LDS_ENT][CL]; };   // 2 x 12.3 KB
 
@@ -413,6 +420,16 @@ __global__ void k_unpack_halo(int ncol, int ng /* layers / CL: (tracer or extra-
   const double2 a = *reinterpret_cast<const double2*>(in), b = *reinterpret_cast<const double2*>(in + 2);
   *reinterpret_cast<double2*>(out) = a; *reinterpret_cast<double2*>(out + 2) = b;
 }
+// received element bounds (compact min/max exchange: [col][min set | max set]) -> behind the local elements of qmin / qmax, where the
+// stage-3 kernel's element ring finds them (entry nelemd + col)
+__global__ void k_unpack_minmax(int ncol, int m /* even */, const double* __restrict__ recvbuf, double* __restrict__ qmin_tail, double* __restrict__ qmax_tail) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, h = (unsigned)m / 2;
+  if (t >= (unsigned)ncol * h) return;
+  const unsigned col = t / h, l = 2 * (t - col * h);
+  const double* in = recvbuf + (size_t)col * 2 * m + l;
+  *reinterpret_cast<double2*>(qmin_tail + (size_t)col * m + l) = *reinterpret_cast<const double2*>(in);
+  *reinterpret_cast<double2*>(qmax_tail + (size_t)col * m + l) = *reinterpret_cast<const double2*>(in + m);
+}
 // the all-zero slot of every chunk of every plane (after a caller used the scratch field as a plain buffer)
 __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned zero0 /* entry index of the zero slot */) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,6 +458,8 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
   static_assert(GIN == 0 || GIN == 1 || (GIN == 3 && RHS == 2), "plain inputs, gathered tracers, or gathered tracers and Laplacian");
   __shared__ PatchLds lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
+  __shared__ BoundsLds bnd_;                    // (GIN == 3 only)
+  constexpr bool NBR = GIN == 3;                // the limiter bounds are the min/max over the element and its neighbours of qmin/qmax, formed here
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
   PatchId pid{};
@@ -500,6 +519,27 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     }
     if (RHS == 2) make_lap_geo(L, g);
   }
+  // NBR: per tracer the block loads the bounds of its patch's elements and of the element ring (lane = 16 bytes: entry, min|max,
+  // level pair) into LDS with the tracer's other loads; after the barrier a lane reads its element's and its 8 neighbours' values
+  unsigned bsrc = 0, bdst = 0, bnb[3] = {0, 0, 0};
+  const double* bbase = qmin;
+  if (NBR) {
+    const int t = threadIdx.x, u = min(t >> 2, BND_ENT - 1), w = (t >> 1) & 1, h = t & 1;   // lanes beyond the image repeat its last entry
+    int el = u < PS ? GA.pslots[pid.patch * PS + u] : GA.pering[pid.patch * NER + (u - PS)];
+    if (el < 0) el = pid.e;   // hole
+    bsrc = (unsigned)((((size_t)el * NCHUNK + kc / CL) * qsize) * CL + h * 2);   // + q*CL: entry index in qmin / qmax (< 2^32: the arrays are < 32 GB)
+    bbase = w ? qmax : qmin;
+    bdst = (unsigned)(((u * 2 + w) * CL + h * 2) * 8);
+    // the 9 entries of a slab (its element, then the 8 neighbours) are shared out over the quad: row j takes entries j, j+4 (and 8)
+    const int sl = pid.live ? pid.slot - pid.patch * PS : 0, kk = kc & (CL - 1);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int d = j + 4 * i;   // 0: the element itself; d >= 1: neighbour d-1
+      int n = sl;
+      if (d >= 1 && d < 9) { const int v = GA.pnb[((size_t)pid.patch * PS + sl) * 8 + (d - 1)]; if (v != 255) n = v; }
+      bnb[i] = (unsigned)((n * 2 * CL + kk) * 8);
+    }
+  }
   const double sumc = quad_sum(((c[0] + c[1]) + c[2]) + c[3]);
   double visc[4];
 #pragma unroll
@@ -516,17 +556,20 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     // pre-DSS output in the scratch layout (chunks of 4 levels, slots, points perimeter first): what the next stage's blocks
     // load as their own points and as their halo ring
     store_row_pair(Tout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.x);
-    if (k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
+    // (stage 3 of the whole-step path: nothing reads the bounds after this stage, the next step starts from fresh ones)
+    if (!NBR && k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
-  GatherRaw graw, graw2;                                 // raw own / ring loads of the gathered input(s) (DSS on read)
-  double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx, maxx;   // plainly loaded inputs of the next tracer
+  GatherRaw graw, graw2;
+  double2 braw = make_double2(0., 0.);                   // NBR: the lane's piece of the bounds image                                 // raw own / ring loads of the gathered input(s) (DSS on read)
+  double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0.0, maxx = 0.0;   // plainly loaded inputs of the next tracer
   auto fetch = [&](int q) {   // loads only
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = mm_idx(e, q, kc, qsize);
     if (GIN) gather_issue(RG, GA, Qn0, q, graw);              // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
     if (GIN == 3) gather_issue(RG, GA, lap, q, graw2);
     if (GIN == 0) load4(Qn0 + so, qnx);
     if (RHS == 2 && GIN != 3) load4(lap + so, lsx);
-    minx = qmin[mi]; maxx = qmax[mi];
+    if (NBR) braw = *reinterpret_cast<const double2*>(bbase + ((size_t)bsrc + (size_t)q * CL));
+    else { minx = qmin[mi]; maxx = qmax[mi]; }
   };
   if (GIN == 3 && threadIdx.x < 2 * CL) lds_[GIN == 3 ? 1 : 0].v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;
   fetch(0);
@@ -536,6 +579,10 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     double qn[4], ls[4] = {0, 0, 0, 0}, own[4], own2[4], minp = minx, maxp = maxx;
     if (GIN) gather_publish(RG, lds_[0], q & 1, kc, graw, own);
     if (GIN == 3) gather_publish(RG, lds_[GIN == 3 ? 1 : 0], q & 1, kc, graw2, own2);
+    if (NBR) {
+      *reinterpret_cast<double2*>(reinterpret_cast<char*>(&bnd_.v[q & 1][0][0][0]) + bdst) = braw;
+      asm volatile("" : : : "memory");   // (written before the next tracer's load reuses braw)
+    }
     if (GIN == 0) {
 #pragma unroll
       for (int i = 0; i < 4; i++) qn[i] = qnx[i];
@@ -555,6 +602,16 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
       lds_barrier();
       gather_sum(RG, lds_[0], q & 1, j, own, qn);
       if (GIN == 3) gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
+    }
+    if (NBR) {   // viscosity_mod.F90:429-432 on the element bounds k_lap1 left in qmin/qmax
+      const char* b = reinterpret_cast<const char*>(&bnd_.v[q & 1][0][0][0]);
+      double mn = *reinterpret_cast<const double*>(b + bnb[0]), mx = *reinterpret_cast<const double*>(b + bnb[0] + CL * 8);
+#pragma unroll
+      for (int i = 1; i < 3; i++) {
+        mn = fmin(mn, *reinterpret_cast<const double*>(b + bnb[i]));
+        mx = fmax(mx, *reinterpret_cast<const double*>(b + bnb[i] + CL * 8));
+      }
+      minp = quad_min(mn); maxp = quad_max(mx);
     }
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
