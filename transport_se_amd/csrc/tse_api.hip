@@ -101,7 +101,7 @@ struct tse_ctx {
   unsigned halo0() const { return (unsigned)(nslots + 1) * 16; }    // entry index of halo column 0
   GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
                    double* var_out = nullptr, int var_out_lev = 0) const {
-    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, pering, pnb};
+    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, nullptr, pering, pnb};
   }
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
@@ -1007,32 +1007,25 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     LAUNCH_CHECK();
   }
   set_bounds_cache(c, 0);
+  // (divdp = div(vn0) has no pass of its own here: stage 1's kernel forms it for its own slab and stores it for the later stages)
   if (halo_ready) {
-    if (tse_compute_divdp(c)) return 1;
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_mm, 0));
-    if (nbr_minmax_kernel(c)) return 1;
-  } else {   // the min/max halo travels under divdp = div(vn0)
-    auto mm_comm = [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs); };
-    hipEvent_t ev0 = nullptr, evM = nullptr;
-    if (c->halo()) {
-      ev0 = next_sync_event(c); evM = next_sync_event(c);
-      HIPCHK(hipEventRecord(ev0, c->stream));
-      HIPCHK(hipStreamWaitEvent(cs, ev0, 0));
-      if (c->comm) { if (mm_comm()) return 1; HIPCHK(hipEventRecord(evM, cs)); }
-    }
-    if (tse_compute_divdp(c)) return 1;
-    if (c->halo()) {
-      if (!c->comm) { if (mm_comm()) return 1; HIPCHK(hipEventRecord(evM, cs)); }
-      HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
-    }
-    if (nbr_minmax_kernel(c)) return 1;
+  } else if (c->halo()) {
+    hipEvent_t ev0 = next_sync_event(c), evM = next_sync_event(c);
+    HIPCHK(hipEventRecord(ev0, c->stream));
+    HIPCHK(hipStreamWaitEvent(cs, ev0, 0));
+    if (pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs)) return 1;
+    HIPCHK(hipEventRecord(evM, cs));
+    HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
   }
+  if (nbr_minmax_kernel(c)) return 1;
   if (split_stage(c, "advance0",
         [&](Work w) -> int {
           if (!w.nwork) return 0;
+          GatherArgs ga = gargs(w, c->divdp_proj, NLEV);
+          ga.divdp_out = c->divdp;
           hipLaunchKernelGGL(k_advance<0>, dim3(flat_blocks(w.nwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)Qn0,
-                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                             gargs(w, c->divdp_proj, NLEV));
+                             (const double*)nullptr, c->T, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, ga);
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->T, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->T, nqv, nqv); })) return 1;
 

@@ -267,6 +267,7 @@ struct GatherArgs {
   const double* var_in;  int var_in_lev;    // producer: plane qsize of the output := spheremp * var_in[e][var_in_lev][p] (levels 0..71)
   double* var_out;       int var_out_lev;   // consumer: rspheremp*DSS(plane qsize of the gathered input) -> var_out[e][var_out_lev][p]
   // stage 3 forms the neighbour min/max of the element bounds itself (min/max half of biharmonic_wk_scalar_minmax):
+  double* divdp_out;               // stage 1 (k_advance<0,0>): divdp = divergence_sphere(vn0) is formed here and stored (no k_divdp pass)
   const int* pering;               // [npatch][NER] elements around the patch (>= nelemd: received entry nelemd + i, stored behind the local elements)
   const unsigned char* pnb;        // [npatch][PS][8] neighbour d of a slot -> entry of the bounds image (slot, PS + ring entry, 255 = none)
 };
@@ -488,21 +489,29 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
     RowGeo g;
     load_row_geo(g, G.dvv, G.Dinv, G.metdet, G.rmetdet, G.spheremp, e, j);
     const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
-    double dpk[4], vs1[4], vs2[4], t0[4], t1[4];
-    load4(dp + lo, dpk); load4(divdp + lo, t1);
+    double dpk[4], vs1[4], vs2[4], t0[4] = {0, 0, 0, 0}, t1[4];
+    const bool mkdiv = RHS == 0 && GIN == 0 && GA.divdp_out;   // divdp = divdp_proj = divergence_sphere(vn0) (prim_advection_mod.F90:614-623)
+    load4(dp + lo, dpk);
+    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
+    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
+    if (mkdiv) {
+      divergence_sphere_row(D, g, vs1, vs2, t1);
+      if (k < NLEV) store4(GA.divdp_out + lo, t1);
+    } else load4(divdp + lo, t1);
     if (GIN && GA.var_out && RHS == 1) {   // divdp_proj = what was just assembled (the array is being written by this launch)
 #pragma unroll
       for (int i = 0; i < 4; i++) t0[i] = vdss[i];
-    } else load4(divdp_proj + lo, t0);
+    } else if (RHS != 0) load4(divdp_proj + lo, t0);
     if (GA.var_in) {   // this stage's extra variable, weighted, as plane qsize of the output
       double vin[4], w[4];
-      load4(GA.var_in + ((size_t)e * GA.var_in_lev + kc) * 16 + j * 4, vin);
+      if (mkdiv) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) vin[i] = t1[i];   // (stage 1's extra variable is divdp_proj = the divergence just formed)
+      } else load4(GA.var_in + ((size_t)e * GA.var_in_lev + kc) * 16 + j * 4, vin);
 #pragma unroll
       for (int i = 0; i < 4; i++) w[i] = g.spheremp[i] * vin[i];
       store_row_pair(Tout + (size_t)qsize * GA.S.tps, RS, kc, k < NLEV, w);
     }
-    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
-    load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       dpk[i] = dpk[i] - RHS * dt * t0[i];
