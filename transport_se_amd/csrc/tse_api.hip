@@ -82,6 +82,7 @@ struct tse_ctx {
   bool halo() const { return ncol_send || ncol_recv; }
   // dcmip
   int dcmip_test = 0;
+  bool dcmip_static = false;   // dp and omega_p hold the prescribed case's time-independent values (p_i(k+1) - p_i(k); 0, which its DSS leaves 0)
   double *lat = nullptr, *lon = nullptr, *zm = nullptr, *zi = nullptr, *pint = nullptr, *dph = nullptr;
   // page-locked range of the host's elem(:) (host_pin) + timing
   uintptr_t pin_lo = 0, pin_hi = 0;            // host range registered with tse_host_register
@@ -539,7 +540,7 @@ int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   return 0;
 }
 int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
-int tse_invalidate_cache(tse_ctx* c) { set_bounds_cache(c, 0); return 0; }
+int tse_invalidate_cache(tse_ctx* c) { set_bounds_cache(c, 0); c->dcmip_static = false; return 0; }
 
 // ---- RCCL communicator ----------------------------------------------------------------------------
 int tse_comm_unique_id(void* id_out) {
@@ -666,6 +667,7 @@ int tse_set_derived(tse_ctx* c, const double* vn0, size_t s0, const double* dp, 
   // vn0(np,np,2,nlev) in Fortran memory is [k][c][p]: the device layout
   if (put_level(c, c->vn0, vn0, s0, 2 * NLEV * 16, 2 * NLEV * 16)) return 1;
   if (dp) set_bounds_cache(c, 0);   // bounds were formed with the previous dp
+  if (dp || omega_p) c->dcmip_static = false;
   if (put_level(c, c->dp, dp, s1, NLEV * 16, NLEV * 16)) return 1;
   if (put_level(c, c->eta, eta, s2, NLEVP * 16, NLEVP * 16)) return 1;
   if (put_level(c, c->omega_p, omega_p, s3, NLEV * 16, NLEV * 16)) return 1;
@@ -1221,7 +1223,7 @@ int tse_element_mass(tse_ctx* c, int nt, double* out) {
 // ---- prescribed fields + device-resident driver ---------------------------------------------------
 int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, const double* hyam, const double* hybm) {
   if (test != 1 && test != 2) return fail("tse_dcmip_init: test_case=%d", test);
-  c->dcmip_test = test;
+  c->dcmip_test = test; c->dcmip_static = false;
   const double H = 287.04 * 300.0 / 9.80616, P0 = 100000.0;
   std::vector<double> hyai(NLEVP), hybi(NLEVP);
   HIPCHK(hipMemcpy(hyai.data(), c->hyai, NLEVP * 8, hipMemcpyDeviceToHost));
@@ -1260,8 +1262,9 @@ int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
   // derived%dp is rewritten with the same time-independent p_i(k+1) - p_i(k) on every step (dcmip_wrapper_mod.F90:183,199), so
   // the cached next-step bounds (formed with that dp) stay valid; every other writer of dp drops them (tse_set_derived)
   hipLaunchKernelGGL(k_dcmip_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
-                     c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dp, c->eta, c->omega_p);
+                     c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dcmip_static ? nullptr : c->dp, c->eta, c->dcmip_static ? nullptr : c->omega_p);
   LAUNCH_CHECK();
+  c->dcmip_static = true;   // until someone else writes dp or omega_p (tse_set_derived, tse_invalidate_cache)
   return 0;
 }
 int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {

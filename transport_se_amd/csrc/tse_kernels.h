@@ -1592,10 +1592,10 @@ __global__ __launch_bounds__(256) void k_dcmip_step(int nelemd, int test, double
       if (test == 1) { u = u_col + u_lev * T->m1[k]; v = v_col; }
       else { u = u_col; v = T->m1[k] * cl * v_col * T->m2[k] * ct_w; }
       const size_t o = ((size_t)e * NLEV + k) * 16 + p;
-      dp[o] = dpr;
+      if (dp) dp[o] = dpr;                 // (null: still holding these time-independent values from an earlier step)
       vn0[(((size_t)e * NLEV + k) * 2 + 0) * 16 + p] = u * dpr;
       vn0[(((size_t)e * NLEV + k) * 2 + 1) * 16 + p] = v * dpr;
-      omega_p[o] = 0.0;
+      if (omega_p) omega_p[o] = 0.0;
     }
   }
 }
