@@ -13,7 +13,6 @@ Without WORLD_SIZE in the environment and N > 1 this script starts the N rank pr
 torch.distributed.run; this parent never touches a GPU) and exits with their status.  Prints ONE JSON line on rank 0.
 """
 import argparse
-import hashlib
 import json
 import os
 import subprocess
@@ -24,6 +23,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_DOF_STEP = 400.0 / 3.0   # 16 2/3 mandatory fp64 field passes per tracer step
+# what the pipeline that is actually built must move: 12 tracer-field passes per step + 2/3 for the remap
+PIPELINE_BYTES_PER_DOF_STEP = (12.0 + 2.0 / 3.0) * 8.0
+BASELINE_PUBLISHED = 3.92e9            # ne120/72L/q35, 960 Edison cores (README:174), other hardware
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per DOF of ONE launch of each kernel (DESIGN.md "kernels"): tracer fields read + written, 8 B each.
 # Default path (DSS on read): advance0 = k_advance<0> (Qdp -> T), advance1 = k_advance<1,1> (T -> B), lap = k_lap1<1>
@@ -39,16 +41,26 @@ if os.environ.get("TSE_DSS_ON_READ", "1") == "0":   # one DSS pass per stage: 4 
 
 def kernel_source_hash():
     """identifies the kernel sources a PMC traffic profile was taken with (tools/pmc_traffic.py stores the same hash)"""
-    h = hashlib.sha256()
-    for f in ("tse_api.hip", "tse_kernels.h", "tse_device.h"):
-        h.update(open(os.path.join(ROOT, "transport_se_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from transport_se_amd import _lib
+    return _lib.source_hash()
 
 
-def measured_traffic(ne, qsize, n_gpus, group):
-    """(HBM bytes per launch of the dominant kernel, source file) from the newest committed PMC passes under profiles/ that
-    were collected with THIS build's kernel sources and workload (collected as MI355X_MICROARCH.md prescribes: separate --pmc
-    runs, FETCH_SIZE doubled on gfx950); (None, reason) otherwise -- counters cannot be read in the timed run itself."""
+def _kernel_entry(kernels, name):
+    """entry of a kernel-keyed profile dict by short name ("k_advance<2,3>"), whatever block-shape parameter follows"""
+    if name in kernels:
+        return kernels[name]
+    stem = name[:-1]   # "k_advance<2,3" matches "k_advance<2,3,32>"
+    for k, v in kernels.items():
+        if k.startswith(stem + ",") or k.startswith(stem + ">"):
+            return v
+    raise KeyError(name)
+
+
+def measured_traffic(ne, qsize, n_gpus, group, launches_per_step):
+    """(HBM bytes per launch of the dominant kernel, HBM bytes per tracer step of all kernels, source file) from the newest
+    committed PMC passes under profiles/ that were collected with THIS build's kernel sources and workload (collected as
+    MI355X_MICROARCH.md prescribes: separate --pmc runs, FETCH_SIZE doubled on gfx950); (None, None, reason) otherwise --
+    counters cannot be read in the timed run itself."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
@@ -58,10 +70,37 @@ def measured_traffic(ne, qsize, n_gpus, group):
                 continue
             if t.get("kernel_source_hash") != kernel_source_hash():
                 continue
-            return t["kernels"][KERNEL_NAMES[group]]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            per_step = 0.0
+            for g, n in launches_per_step.items():
+                if g in KERNEL_NAMES and n:
+                    per_step += _kernel_entry(t["kernels"], KERNEL_NAMES[g])["hbm_bytes_per_launch"] * n
+            for k, v in t["kernels"].items():   # the small kernels: one launch per step each
+                if k.startswith("k_nbr_minmax") or k.startswith("k_dcmip_step"):
+                    per_step += v["hbm_bytes_per_launch"]
+            return _kernel_entry(t["kernels"], KERNEL_NAMES[group])["hbm_bytes_per_launch"], per_step, os.path.relpath(path, ROOT)
         except Exception:  # noqa: BLE001
             continue
-    return None, "no PMC profile of this build and workload under profiles/"
+    return None, None, "no PMC profile of this build and workload under profiles/"
+
+
+def l2_record(ne):
+    """the second half of the metric ("+ DCMIP1-1 L2 vs ref"): the 12-day DCMIP 1-1 error norm at this resolution from the newest
+    committed record under profiles/ that was produced with THIS build's kernel sources (tests/test_gpu_dcmip_norms.py writes
+    it in every -m gpu session; 4-6 GPU-minutes at ne120, so it cannot run inside the timed bench)."""
+    import glob
+    ref = {120: 0.782613, 30: 0.789052, 8: 0.865526}.get(ne)   # /root/reference/README:152,128,95
+    last = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*l2_dcmip11_ne%d*.json" % ne)), reverse=True):
+        try:
+            r = json.load(open(path))
+        except Exception:  # noqa: BLE001
+            continue
+        last = last or (r.get("kernel_source_hash"), os.path.relpath(path, ROOT))
+        if r.get("kernel_source_hash") == kernel_source_hash():
+            return {"value": r["L2"], "ref": ref, "rel_err": abs(r["L2"] - ref) / ref if ref else None, "L1": r.get("L1"), "Linf": r.get("Linf"),
+                    "config": r.get("config"), "source": os.path.relpath(path, ROOT)}
+    return {"value": None, "ref": ref, "rel_err": None, "config": None, "source": None,
+            "reason": "no record of this build's kernel sources under profiles/" + (" (newest: %s, hash %s)" % (last[1], last[0]) if last else "")}
 
 
 def host_cores():
@@ -95,7 +134,7 @@ def cpu_baseline(qsize):
     cores = int(os.environ.get("TSE_CPU_RANKS", usable))
     where = "%d ranks on %d usable of %d logical CPUs, %d socket(s)" % (cores, usable, total, sockets)
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    vdir = os.path.join(ROOT, "tests", "golden", "vcoord")
+    vdir = os.path.join(ROOT, "transport_se_amd", "data", "vcoord")
     ne, nsteps = int(os.environ.get("TSE_CPU_NE", "30")), 6
     if os.path.exists(harness) and os.path.exists("/opt/conda/bin/mpiexec"):
         try:
@@ -112,7 +151,11 @@ def cpu_baseline(qsize):
                     v = float(line.split("=")[1])
                     return dict(value=v, unit="tracer-DOF-steps/s", cores=cores, kind="reference",
                                 sample="ne%d/72L/qsize=%d DCMIP1-1, %d tracer steps + 2 remaps (prim_run region), reference Fortran/MPI: %s"
-                                       % (ne, qsize, nsteps, where))
+                                       % (ne, qsize, nsteps, where),
+                                why_sample="the reference at ne120/qsize=35 keeps elem(:) + its stack scratch + edge buffers (Qdp alone 55.7 GB, "
+                                           "Qtens_biharmonic 27.9 GB per rank set, edge buffers sized 3*qsize*nlev per column): about 0.45 TB of host RAM "
+                                           "and minutes per step on the %d cores a 1-GPU box grants; ne30/qsize=35 (1.7 GB per field, far beyond the caches) "
+                                           "runs the same bandwidth-bound code in about 20 s" % cores)
             print("cpu_baseline: reference harness printed no rate:\n" + res.stdout.decode()[-800:], file=sys.stderr)
         except Exception as ex:  # noqa: BLE001
             print("cpu_baseline: reference harness failed (%s); using the C port" % ex, file=sys.stderr)
@@ -190,7 +233,8 @@ def main():
             dist.barrier()
         run.hip.synchronize(); torch.cuda.synchronize()
 
-    # warm-up leaves the time loop at a multiple of rsplit so the timed K steps contain K/rsplit remaps
+    # (the timed K steps contain floor((W + K) / rsplit) - floor(W / rsplit) remaps: K/rsplit when W is a multiple of rsplit, one
+    # more otherwise -- the count is in the JSON line as remaps_in_timed_region)
     run.run(a.warmup)
     barrier()
     run.hip.timing(True)
@@ -220,12 +264,18 @@ def main():
         ms, n = ktimes[dom]
         dof_local = float(run.mine.size) * 16 * 72 * a.qsize
         ach = (KERNEL_BYTES_PER_DOF[dom] * dof_local / 1e9) / (ms / max(n, 1) / 1e3) if ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic(a.ne, a.qsize, world, dom)
+        launches_per_step = {k: ktimes[k][1] / a.steps for k in KERNEL_NAMES}
+        traffic, traffic_step, traffic_src = measured_traffic(a.ne, a.qsize, world, dom, launches_per_step)
         nb, ni = run.hip.boundary_layout()
+        rccl = run.hip.comm_version()
+        pipe_bytes_step = PIPELINE_BYTES_PER_DOF_STEP * dof_local   # per GPU and tracer step
         out = {
             "metric": "advected tracer-DOF/sec (ne%d, 72L, qsize=%d) + DCMIP1-1 L2 vs ref" % (a.ne, a.qsize),
             "value": value, "unit": "tracer-DOF-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "strong",
+            # the reference's own published rate for this metric and config (960 Edison cores, README:174)
+            "vs_baseline": value / BASELINE_PUBLISHED if (a.ne, a.qsize) == (120, 35) else None,
+            "remaps_in_timed_region": int(ktimes["remap"][1]),
             "dtype": "f64", "data": "synthetic (analytic DCMIP 1-1 fields, no files)",
             "config": {"workload": "ne%d DCMIP1-1 prim_run, NP=4, 72L, qsize=%d, rsplit=3, limiter8, nu_q=%g, tstep=%g; "
                                    "%d elements sharded over %d GPU(s) along the space-filling curve"
@@ -238,7 +288,16 @@ def main():
             "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "avg_ms": ms / max(n, 1), "launches": n,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
-                         "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (world * HBM_PEAK_GBS * 1e9)},
+                         # whole step against SURVEY 8(d)'s 133.3 B per DOF-step (kept for continuity between rounds) ...
+                         "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (world * HBM_PEAK_GBS * 1e9),
+                         # ... and against the bytes THIS pipeline must move (12 2/3 field passes = 101.3 B per DOF-step)
+                         "pipeline_alg_bytes_per_dof_step": PIPELINE_BYTES_PER_DOF_STEP,
+                         "whole_step_frac_pipeline": value * PIPELINE_BYTES_PER_DOF_STEP / (world * HBM_PEAK_GBS * 1e9),
+                         # counter traffic of all kernels of one tracer step (same PMC profile; remap weighted by its launch rate)
+                         "traffic_total_per_step": traffic_step,
+                         "traffic_ratio_vs_pipeline": traffic_step / pipe_bytes_step if traffic_step else None},
+            "l2_dcmip11": l2_record(a.ne),
+            "rccl": rccl,
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in ktimes.items()},
             "kernel_source_hash": kernel_source_hash(),
             # wrap-around int64 sum of the bit patterns of the final Qdp over all ranks: equal for every --gpus N

@@ -77,6 +77,8 @@ typedef struct {
   int nsend; const int *send_peer; const int *send_ptrP; const int *send_lengthP;
   int nrecv; const int *recv_peer; const int *recv_ptrP; const int *recv_lengthP;
   tse_exchange_fn exchange; void *exchange_user;   /* may be NULL when nsend == nrecv == 0, or when tse_comm_init follows */
+  int vert_remap_q_alg; /* control_mod vert_remap_q_alg (control_mod.F90:61-66): 0|1 = PPM with mirrored ghost cells, 2 = PPM with
+                         * piecewise-constant boundary cells (prim_advection_mod.F90:230-250,283-341); anything else is refused */
 } tse_init_args;
 
 int  tse_init(tse_ctx **ctx, const tse_init_args *args);
@@ -95,6 +97,14 @@ int  tse_synchronize(tse_ctx *ctx);
 #define TSE_COMM_ID_BYTES 128
 int tse_comm_unique_id(void *id_out /* TSE_COMM_ID_BYTES */);
 int tse_comm_init(tse_ctx *ctx, const void *id /* TSE_COMM_ID_BYTES */, int rank, int nranks);
+/* Everything tse_comm_init can find wrong WITHOUT the other ranks: rank/peer ranges, device, streams, and that the RCCL this
+ * process resolved can serve the headers the library was built with (same major version, point-to-point capable).  ncclCommInitRank is a blocking collective, so
+ * a host calls this on every rank first, agrees on the outcome over its own control plane (MPI_Allreduce, gloo) and enters
+ * tse_comm_init only when every rank is ready -- a rank that failed alone inside tse_comm_init would strand its peers. */
+int tse_comm_precheck(tse_ctx *ctx, int rank, int nranks);
+/* the RCCL this process runs: version code of the runtime (ncclGetVersion: major*10000 + minor*100 + patch), of the headers
+ * the library was built with, and the path of the shared object that provides it (bench.py prints all three) */
+int tse_comm_version(int *runtime, int *built, char *path, size_t path_len);
 /* rank / size as the communicator itself reports them (ncclCommUserRank/ncclCommCount); 0/1 without a communicator */
 int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
 /* give the communicator up (ncclCommAbort; no-op without one): afterwards the halo goes through the exchange callback of
@@ -162,7 +172,10 @@ int tse_dcmip_init(tse_ctx *ctx, int test_case /*1: dcmip1-1, 2: dcmip1-2*/, con
 int tse_dcmip_set_initial(tse_ctx *ctx);
 /* what prim_step + prim_advance_exp produce for the step that starts at tl%nstep = nstep */
 int tse_dcmip_step_inputs(tse_ctx *ctx, int nstep, double tstep);
-/* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out */
+/* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out.
+ * Returns 2 on "negative layer thickness" (prim_advection_mod.F90:1323) with *nstep = the step count at the end of the FIRST
+ * failing cycle; the flag is polled two cycles behind the launches (the host never waits for the device), so up to two
+ * further cycles may have been started on the bad state.  Several ranks: escalate as for tse_vertical_remap. */
 int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
 
 /* ---- diagnostics ---- */

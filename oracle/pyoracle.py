@@ -11,7 +11,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NLEV, NLEVP, NP = 72, 73, 4
-VCOORD_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden", "vcoord")
+VCOORD_DIR = os.path.join(os.path.dirname(HERE), "transport_se_amd", "data", "vcoord")   # the one copy of the ACME 72-level tables (data)
 
 
 def read_vcoord(vdir=VCOORD_DIR):
@@ -63,6 +63,7 @@ def lib():
         L.orc_limiter8.restype = C.c_int
         L.orc_limiter8.argtypes = [dp, dp, dp, dp, dp]
         L.orc_remap_q_ppm.argtypes = [dp, C.c_int, dp, dp]
+        L.orc_set_vert_remap_q_alg.argtypes = [C.c_int]
         L.orc_dss.argtypes = [C.c_void_p, dp, C.c_int, C.c_int]
         L.orc_euler_step.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int]
         L.orc_advec_tracers_remap_rk2.argtypes = [C.c_void_p, C.c_double, C.c_int]
@@ -165,6 +166,11 @@ def limiter8(ptens, sphweights, minp, maxp, dpmass):
     it = lib().orc_limiter8(_p(pt), _p(np.ascontiguousarray(sphweights, dtype=np.float64).reshape(16)),
                             C.byref(mn), C.byref(mx), _p(np.ascontiguousarray(dpmass, dtype=np.float64).reshape(16)))
     return pt.reshape(4, 4), mn.value, mx.value, it
+
+
+def set_vert_remap_q_alg(alg):
+    """control_mod's vert_remap_q_alg for every later remap of this process (0|1 mirrored ghosts, 2 piecewise-constant ends)"""
+    lib().orc_set_vert_remap_q_alg(int(alg))
 
 
 def remap_q_ppm(Qdp, dp1, dp2):

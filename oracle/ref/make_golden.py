@@ -8,6 +8,7 @@ Only data is written (inputs and expected outputs); no reference source travels.
     python oracle/ref/make_golden.py            # ne2 fixtures (seconds)
     python oracle/ref/make_golden.py --long     # + ne8 12-day DCMIP 1-1 / 1-day 1-2 norms (minutes, 6 ranks)
     python oracle/ref/make_golden.py --sfc      # only the space-filling-curve partition fixture (ref_sfc_partition.npz)
+    python oracle/ref/make_golden.py --alg2     # only the vert_remap_q_alg=2 fixture (ref_ne2_alg2.npz)
 """
 import argparse
 import json
@@ -30,13 +31,30 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
-def run(ne, qsize, nsteps, tstep, nu_q, test, dumpfreq, nranks=1, outdir=None):
+def run(ne, qsize, nsteps, tstep, nu_q, test, dumpfreq, nranks=1, outdir=None, env=None):
+    """env: namelist overrides the harness takes from the environment (TSE_NL_VERT_REMAP_Q_ALG, ...)"""
     outdir = outdir or tempfile.mkdtemp(prefix="tse_ref_")
     os.makedirs(outdir, exist_ok=True)
     stdin = "%d %d %d %r %r %d %d\n'%s'\n'%s'\n" % (ne, qsize, nsteps, tstep, nu_q, test, dumpfreq, outdir, VCOORD)
     res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS], input=stdin.encode(), stdout=subprocess.PIPE,
-                         stderr=subprocess.STDOUT, check=True)
+                         stderr=subprocess.STDOUT, check=True, env=dict(os.environ, **(env or {})))
     return outdir, res.stdout.decode()
+
+
+def make_alg2():
+    """vert_remap_q_alg = 2 (control_mod.F90:61-66; prim_advection_mod.F90:230-250,283-341): the reference's own single-call
+    remap_Q_ppm outputs and a 6-step DCMIP 1-1 run (two remaps) with the piecewise-constant boundary cells."""
+    cfg = dict(ne=2, qsize=5, nsteps=6, tstep=1800.0, nu_q=1e19, test=1)
+    outdir, _ = run(dumpfreq=0, env={"TSE_NL_VERT_REMAP_Q_ALG": "2"}, **cfg)
+    _, remaps = po.read_ops(os.path.join(outdir, "ops_000000_r0000.bin"))
+    s6 = po.read_state(os.path.join(outdir, "state_000006_r0000.bin"))
+    np.savez_compressed(
+        os.path.join(GOLD, "ref_ne2_alg2.npz"), config=json.dumps(dict(cfg, vert_remap_q_alg=2)),
+        remap_dp1=np.array([r["dp1"] for r in remaps]), remap_dp2=np.array([r["dp2"] for r in remaps]),
+        remap_Qin=np.array([r["Qin"] for r in remaps]), remap_Qout=np.array([r["Qout"] for r in remaps]),
+        qdp_step6=s6["qdp"], dp3d_step6=s6["dp3d"], ps_v_step6=s6["ps_v"])
+    ref0 = np.load(os.path.join(GOLD, "ref_ne2_dcmip11.npz"))
+    print("alg 2 vs alg 0 after 6 steps: max |diff| / max = %.3e" % (np.abs(s6["qdp"] - ref0["qdp_step6"]).max() / np.abs(s6["qdp"]).max()))
 
 
 def make_ne2():
@@ -141,11 +159,15 @@ if __name__ == "__main__":
     ap.add_argument("--sfc", action="store_true")
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--only-long", action="store_true")
+    ap.add_argument("--alg2", action="store_true", help="only the vert_remap_q_alg=2 fixture (ref_ne2_alg2.npz)")
     a = ap.parse_args()
     if not os.path.exists(HARNESS):
         subprocess.check_call(["make", "-C", HERE])
     if a.sfc:
         make_sfc()
+        sys.exit(0)
+    if a.alg2:
+        make_alg2()
         sys.exit(0)
     if not a.only_long:
         make_ne2()

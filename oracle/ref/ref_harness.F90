@@ -102,6 +102,13 @@ program ref_harness
   hypervis_power = 0; hypervis_scaling = 0
   qsplit = 1; rsplit = 3; tstep_type = 1; integration = "explicit"
   cubed_sphere_map = 0
+  ! optional namelist overrides through the environment (make_golden.py --alg2; the seam-guard tests of the drop-in harness):
+  ! TSE_NL_VERT_REMAP_Q_ALG, TSE_NL_QSPLIT, TSE_NL_HYPERVIS_SUBCYCLE_Q, TSE_NL_HYPERVIS_POWER, TSE_NL_HYPERVIS_SCALING
+  call env_int('TSE_NL_VERT_REMAP_Q_ALG', vert_remap_q_alg)
+  call env_int('TSE_NL_QSPLIT', qsplit)
+  call env_int('TSE_NL_HYPERVIS_SUBCYCLE_Q', hypervis_subcycle_q)
+  call env_real('TSE_NL_HYPERVIS_POWER', hypervis_power)
+  call env_real('TSE_NL_HYPERVIS_SCALING', hypervis_scaling)
   if (tcase == 1) then
      test_case = "dcmip1-1"
   else
@@ -245,6 +252,23 @@ program ref_harness
   call haltmp('ref_harness done')
 
 contains
+
+  subroutine env_int(name, v)
+    character(len=*), intent(in) :: name
+    integer, intent(inout) :: v
+    character(len=64) :: txt
+    integer :: stat
+    call get_environment_variable(name, txt, status=stat)
+    if (stat == 0 .and. len_trim(txt) > 0) read(txt, *) v
+  end subroutine env_int
+  subroutine env_real(name, v)
+    character(len=*), intent(in) :: name
+    real(kind=real_kind), intent(inout) :: v
+    character(len=64) :: txt
+    integer :: stat
+    call get_environment_variable(name, txt, status=stat)
+    if (stat == 0 .and. len_trim(txt) > 0) read(txt, *) v
+  end subroutine env_real
 
   ! prim_step (prim_driver_mod.F90:856-943) + prim_advance_exp (prim_advance_mod.F90:62-152), ur_weights(1)=1
   subroutine my_prim_step()

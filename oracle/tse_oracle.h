@@ -62,6 +62,9 @@ int orc_limiter8(double ptens[16], const double sphweights[16], double *minp, do
 
 /* remap_Q_ppm for one element: Qdp[q][k][p] in/out, dp1/dp2[k][p] (prim_advection_mod.F90:98-214) */
 void orc_remap_q_ppm(double *Qdp, int qsize, const double *dp1, const double *dp2);
+/* control_mod's vert_remap_q_alg (control_mod.F90:61-66) for every later remap of this process: 0|1 mirrored ghost cells
+ * (default), 2 piecewise-constant boundary cells (prim_advection_mod.F90:230-250,283-341) */
+void orc_set_vert_remap_q_alg(int alg);
 
 /* DSS of an arbitrary nlyr-layer field f[ie][lyr][p] (edgeVpack + bndry_exchangeV + edgeVunpack,
  * edge_mod.F90:366-511,648-742), op: 0 sum, 1 min, 2 max */

@@ -1,6 +1,6 @@
 """-m gpu: the drop-in boundary exercised from the reference's own language.
 
-transport_se_amd/fortran/_build/hip_harness is the reference's UNMODIFIED prim_advection_mod.F90 compiled with
+tests/fortran_dropin/_build/hip_harness (tests/fortran_dropin/Makefile) is the reference's UNMODIFIED prim_advection_mod.F90 compiled with
 -DUSE_CUDA_FORTRAN=1 and linked against transport_se_amd/fortran/cuda_mod_hip.F90 (a Fortran module named `cuda_mod`
 bound to libtransport_se_hip.so with ISO_C_BINDING): the reference's own `call euler_step_cuda(...)`,
 `call qdp_time_avg_cuda(...)`, `call vertical_remap_cuda(...)` hooks run on the MI355X.  Its output must equal the
@@ -18,7 +18,7 @@ import pyoracle as po
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HARNESS = os.path.join(ROOT, "transport_se_amd", "fortran", "_build", "hip_harness")
+HARNESS = os.path.join(ROOT, "tests", "fortran_dropin", "_build", "hip_harness")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 
 
@@ -35,7 +35,7 @@ def test_reference_hooks_drive_the_hip_library(gold, whole_step):
     cfg = json.loads(str(g["config"]))
     out = tempfile.mkdtemp(prefix="tse_f90_")
     stdin = "%d %d %d %r %r %d 1\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
-                                                 out, os.path.join(ROOT, "tests", "golden", "vcoord"))
+                                                 out, os.path.join(ROOT, "transport_se_amd", "data", "vcoord"))
     res = subprocess.run([MPIEXEC, "-n", "1", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
                          env=_env(whole_step))
     log = res.stdout.decode()
@@ -59,7 +59,7 @@ def test_reference_hooks_multirank_mpi_exchange(gold, nranks, whole_step):
     cfg = json.loads(str(g["config"]))
     out = tempfile.mkdtemp(prefix="tse_f90mr_")
     stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
-                                                 out, os.path.join(ROOT, "tests", "golden", "vcoord"))
+                                                 out, os.path.join(ROOT, "transport_se_amd", "data", "vcoord"))
     res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
                          env=_env(whole_step))
     log = res.stdout.decode()
@@ -84,7 +84,7 @@ def test_rccl_mode_falls_back_to_the_mpi_exchange_when_the_communicator_cannot_b
     cfg = json.loads(str(g["config"]))
     out = tempfile.mkdtemp(prefix="tse_f90fb_")
     stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
-                                                 out, os.path.join(ROOT, "tests", "golden", "vcoord"))
+                                                 out, os.path.join(ROOT, "transport_se_amd", "data", "vcoord"))
     res = subprocess.run([MPIEXEC, "-n", "2", HARNESS], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
                          env=dict(_env(True), TSE_EXCHANGE="rccl"))
     log = res.stdout.decode()

@@ -217,6 +217,59 @@ def test_negative_layer_thickness_is_reported(ctx5):
         hip.vertical_remap(1.0e9, 2)
 
 
+def test_prim_run_subcycle_names_the_failing_cycle():
+    """the device-resident loop polls the remap's negative-thickness flag two cycles behind its launches: a failure in a cycle
+    must come back as rc 2 with the step count at the END OF THAT CYCLE (the reference aborts in the first failing remap,
+    prim_advection_mod.F90:1323), however many cycles were asked for -- not as the full count after stepping on garbage"""
+    from transport_se_amd.hip_mod import TseError
+    o = po.Oracle(2, 2, nu_q=1e19)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm)
+    hip.dcmip_set_initial()
+    assert hip.prim_run_subcycle(1800.0, 2, 0) == 6          # healthy cycles first
+    with pytest.raises(TseError, match="negative layer thickness") as ei:
+        hip.prim_run_subcycle(3.0e7, 5, 6)                    # a time step that empties layers in the first remap
+    assert ei.value.rc == 2 and ei.value.nstep == 9, (ei.value.rc, ei.value.nstep)
+    # the flag is consumed: the context works again
+    hip.dcmip_set_initial()
+    assert hip.prim_run_subcycle(1800.0, 1, 0) == 3
+    hip.close(); o.close()
+
+
+def test_operator_call_does_not_leave_its_dp_behind():
+    """tse_remap_q_ppm uses the level fields as work space (it overwrites derived%dp with the caller's dp1).  The prescribed-wind
+    generator skips rewriting the time-independent dp/omega_p while nobody else has touched them -- an operator-level call in
+    between must make it write them again: steps, remap_q_ppm, steps == the uninterrupted run, bit for bit"""
+    o = po.Oracle(2, 5, nu_q=1e19)
+    elem = elem_from_oracle(o)
+    rng = np.random.default_rng(11)
+    dp1 = 1000.0 * (1 + 0.2 * rng.random((o.nelem, 72, 4, 4)))
+    dp2 = dp1 * (1 + 0.05 * (rng.random(dp1.shape) - 0.5)); dp2 *= dp1.sum(1, keepdims=True) / dp2.sum(1, keepdims=True)
+    Qop = rng.random((o.nelem, 5, 72, 4, 4)) * dp1[:, None]
+
+    def run(interrupt):
+        hip = make_hip(o, elem)
+        hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm)
+        hip.dcmip_set_initial()
+        assert hip.prim_run_subcycle(1800.0, 1, 0) == 3
+        if interrupt:
+            q = hip.fetch("qdp", (2, o.nelem, 5, 72, 4, 4)).copy()
+            hip.remap_q_ppm(Qop, dp1, dp2)
+            elem["Qdp"][...] = np.moveaxis(q, 0, 1)       # put the tracer state back (the call used time level 1 as work space)
+            hip.copy_qdp_h2d(elem, 1); hip.copy_qdp_h2d(elem, 2)
+        assert hip.prim_run_subcycle(1800.0, 1, 3) == 6
+        out = hip.fetch("qdp", (2, o.nelem, 5, 72, 4, 4)).copy()
+        dp = hip.fetch("dp", (o.nelem, 72, 4, 4)).copy()
+        hip.close()
+        return out, dp
+    a, dpa = run(False)
+    b, dpb = run(True)
+    assert np.array_equal(dpa, dpb), "derived%dp still holds the operator call's dp1"
+    assert np.array_equal(a, b)
+    o.close()
+
+
 @pytest.mark.parametrize("nt,generic,squeeze", [(1, 0, False), (2, 0, False), (2, 1, False), (1, 0, True), (2, 0, True)])
 def test_remap_column_loop_variants(ctx5, monkeypatch, nt, generic, squeeze):
     """k_remap's lockstep column loop (kid(k) in {k,k+1}; 1 or 2 tracers per thread) and its generic loop against the

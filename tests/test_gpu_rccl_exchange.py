@@ -100,7 +100,7 @@ def test_halo_without_transport_fails_loudly():
     h.dcmip_set_initial()
     with pytest.raises(TseError, match="neither tse_comm_init"):
         h.prim_run_subcycle(1800.0, 1, 0)
-    with pytest.raises(TseError, match="outside the 1-rank communicator"):
+    with pytest.raises(TseError, match=r"tse_comm_precheck: send peer 1 \(this is rank 0 of 1\)"):
         h.comm_init(HipMod.comm_unique_id(), 0, 1)     # peer rank 1 does not exist in a 1-rank communicator
     h.close()
 
@@ -178,6 +178,43 @@ def test_ranks_that_cannot_build_a_communicator_fall_back_together(tmp_path):
     assert res["comm"] == [0, 1]                      # no communicator left behind
     assert b"WARNING: RCCL communicator" in r.stderr
     assert res["checksum"] == ref
+
+
+def test_one_rank_failing_its_precheck_takes_every_rank_off_rccl(tmp_path):
+    """ncclCommInitRank is a blocking collective: a rank that cannot take part (bad peer table, no device, another librccl
+    loaded ...) must be found BEFORE anyone enters it, or its peers wait in the bootstrap for ever.  Here rank 1 alone fails
+    tse_comm_precheck (TSE_TEST_FAIL_PRECHECK_RANK); the ranks agree on that over the control plane, nobody calls
+    tse_comm_init, all continue on the host-staged callback and the result has the bits of the single-rank run."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from transport_se_amd.driver import PrimRun
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    one = PrimRun(4, 2, device=0, torch_mod=torch)
+    ref = one.state_checksum(one.run(3), torch)
+    one.close()
+    w = tmp_path / "worker.py"
+    w.write_text(_FALLBACK_WORKER)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29635", str(w), root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                       env=dict(os.environ, TSE_TEST_FAIL_PRECHECK_RANK="1"))
+    out = r.stdout.decode()
+    assert r.returncode == 0, out + r.stderr.decode()[-2000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:])
+    assert res["exchange"] == "staged" and "rank(s) 1 " in res["note"] and "fails on request" in res["note"], res["note"]
+    assert res["comm"] == [0, 1] and res["checksum"] == ref
+
+
+def test_rccl_version_is_reported_and_matches_the_headers():
+    """tse_comm_version: the RCCL this process resolved (version + path of the shared object) against the headers the library was
+    built with -- bench.py prints it; a major.minor mismatch is refused by tse_comm_precheck"""
+    from transport_se_amd.hip_mod import HipMod
+    v = HipMod.comm_version()
+    assert v["path"].endswith(".so") or ".so." in v["path"], v
+    assert v["runtime"].split(".")[0] == v["built"].split(".")[0], v      # same major version (tse_comm_precheck refuses anything else)
+    import torch
+    assert os.path.dirname(torch.__file__) in v["path"], v                # one RCCL per process: the copy torch loaded
 
 
 def test_rank_rehearsal_tool_runs_one_rank_of_a_partition_in_loopback():

@@ -154,3 +154,25 @@ def test_dss_continuity_and_q1_preserved(o5):
     o5.advec_tracers_remap_rk2(1800.0, 0)
     dp_end = o5.dp - 1800.0 * o5.divdp_proj          # dp after the three half-steps averaged: (dp + 2*(dp-1.5dt div))/3
     np.testing.assert_allclose(o5.qdp[1][:, 4] / dp_end, 1.0, rtol=5e-12)
+
+
+def test_remap_alg2_bit_exact_vs_reference(gold):
+    """vert_remap_q_alg = 2 (piecewise-constant boundary cells, prim_advection_mod.F90:230-250,283-341): the restatement against the
+    reference's own outputs with that namelist value (oracle/ref/make_golden.py --alg2): single calls and a 6-step run with two remaps"""
+    import json
+    g = gold("ref_ne2_alg2.npz")
+    cfg = json.loads(str(g["config"]))
+    po.set_vert_remap_q_alg(2)
+    try:
+        for i in range(2):
+            out = po.remap_q_ppm(g["remap_Qin"][i], g["remap_dp1"][i], g["remap_dp2"][i])
+            assert np.array_equal(out, g["remap_Qout"][i])
+        o = po.Oracle(cfg["ne"], cfg["qsize"], nu_q=cfg["nu_q"])
+        o.dcmip_init(1)
+        done, _ = o.prim_run(1, cfg["tstep"], 2)
+        assert done == 6 and np.array_equal(o.qdp[0], g["qdp_step6"])
+        o.close()
+    finally:
+        po.set_vert_remap_q_alg(0)
+    # the default algorithm does not reproduce them
+    assert not np.array_equal(po.remap_q_ppm(g["remap_Qin"][0], g["remap_dp1"][0], g["remap_dp2"][0]), g["remap_Qout"][0])

@@ -12,7 +12,7 @@ def short(n):
     if m:
         t = re.findall(r"L[ib](\d+)E", m.group(2) or "")
         if m.group(1) == "k_advance":
-            t = t[:2]          # <RHS, GIN>; the third flag (double-buffered stores) follows from GIN
+            t = t[:2] + t[3:]  # <RHS, GIN[, PSZ]>; the third flag (double-buffered stores) follows from GIN
         return m.group(1) + ("<" + ",".join(t) + ">" if t else "")
     return n[:60]
 tot = sum(r[3] for r in rows)

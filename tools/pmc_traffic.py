@@ -15,8 +15,9 @@ def short(n):
     if not m:
         return None
     t = (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
-    if m.group(1) == "k_advance" and t.count(",") == 2:
-        t = t[:t.rindex(",")] + ">"           # drop the DB flag
+    if m.group(1) == "k_advance" and t.count(",") >= 2:
+        parts = t[1:-1].split(",")            # <RHS, GIN, DB[, PSZ]>: drop the DB flag, keep the block shape
+        t = "<" + ",".join(parts[:2] + parts[3:]) + ">"
     return m.group(1) + t
 
 
@@ -45,11 +46,9 @@ for k, c in sorted(acc.items()):
         e["l2_hit_rate"] = h / (h + m) if h + m else None
         e["tcc_miss_x128B_per_launch"] = m / len(c["TCC_MISS_sum"]) * 128
     kern[k] = e
-import hashlib
-_h = hashlib.sha256()
-for _f in ("tse_api.hip", "tse_kernels.h", "tse_device.h"):   # the same hash bench.py prints: ties the counters to a build
-    _h.update(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "transport_se_amd", "csrc", _f), "rb").read())
-json.dump({"config": {"ne": ne, "nlev": 72, "qsize": qsize, "n_gpus": ngpu}, "kernel_source_hash": _h.hexdigest()[:16],
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transport_se_amd import _lib   # the same hash bench.py prints: ties the counters to a build
+json.dump({"config": {"ne": ne, "nlev": 72, "qsize": qsize, "n_gpus": ngpu}, "kernel_source_hash": _lib.source_hash(),
            "command": "tools/pmc_passes.sh: rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py --steps 3 --warmup 0 "
                       "--no-cpu-baseline, C in {FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum} (separate passes)",
            "corrections": __doc__.split("Corrections", 1)[1].strip(), "kernels": kern}, open(out, "w"), indent=1)

@@ -23,6 +23,7 @@ class InitArgs(C.Structure):
         ("nsend", C.c_int), ("send_peer", C.c_void_p), ("send_ptrP", C.c_void_p), ("send_lengthP", C.c_void_p),
         ("nrecv", C.c_int), ("recv_peer", C.c_void_p), ("recv_ptrP", C.c_void_p), ("recv_lengthP", C.c_void_p),
         ("exchange", EXCHANGE_FN), ("exchange_user", C.c_void_p),
+        ("vert_remap_q_alg", C.c_int),
     ]
 
 
@@ -41,6 +42,15 @@ def build(force=False, verbose=False):
     return SO
 
 
+def source_hash():
+    """identifies the kernel sources a committed measurement (profiles/*pmc_traffic*, *l2_dcmip11*) was taken with"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SRC:
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 
 # every symbol include/transport_se_hip.h declares
@@ -48,7 +58,7 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_set_derived", "tse_set_divdp", "tse_get_derived", "tse_advec_tracers_remap_rk2", "tse_compute_divdp", "tse_euler_step",
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
-           "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_info", "tse_comm_abort",
+           "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_precheck", "tse_comm_version", "tse_comm_info", "tse_comm_abort",
            "tse_boundary_layout", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass"]
 COMM_ID_BYTES = 128
 
@@ -61,6 +71,16 @@ def lib():
     if not os.path.exists(SO):
         raise RuntimeError("libtransport_se_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback for the product path)")
+    # One HIP runtime and one RCCL per process.  PyTorch (the control plane of the multi-rank driver, and what the benchmark
+    # contract synchronises with) loads the ROCm libraries bundled in its wheel by absolute path; a libamdhip64 / librccl that is
+    # already in the process under the same SONAME does not stop it, so "library first, torch later" ends with TWO runtimes
+    # (device pointers of one unknown to the other: hipErrorNoDevice on the first copy).  The other order is safe: this
+    # library's DT_NEEDED entries (libamdhip64.so.7, librccl.so.1) resolve to the copies torch has loaded.  So torch goes first
+    # whenever it is installed; tse_comm_version() reports which RCCL that is (bench.py prints it).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(os.environ.get("TSE_LIB", SO))   # TSE_LIB: A/B builds of the same sources (tools/), never a fallback
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     L.tse_init.argtypes = [C.POINTER(vp), C.POINTER(InitArgs)]
@@ -89,6 +109,8 @@ def lib():
     L.tse_halo_minmax_layout.argtypes = [vp, vp, vp]
     L.tse_comm_unique_id.argtypes = [vp]
     L.tse_comm_init.argtypes = [vp, vp, i, i]
+    L.tse_comm_precheck.argtypes = [vp, i, i]
+    L.tse_comm_version.argtypes = [C.POINTER(i), C.POINTER(i), C.c_char_p, sz]
     L.tse_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.tse_comm_abort.argtypes = [vp]
     L.tse_boundary_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]

@@ -8,6 +8,7 @@
 // same way: cuda_mod.F90:358-401,961-1005; the exchange it replaces is bndry_mod.F90:74-124).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -38,8 +39,21 @@ static int fail(const char* fmt, ...) {
 
 struct KTimer { double ms = 0; long n = 0; };
 
+// the tables of one patch tiling (tse_kernels.h: Patch<PSZ>): built for the 4 x 4 storage tiling and for every wider block
+// shape some kernel was given
+struct PatchSet {
+  int psz = 0, npatch = 0, np_bnd = 0, np_int = 0;
+  int *pslots = nullptr, *plist_bnd = nullptr, *plist_int = nullptr, *pering = nullptr;
+  unsigned* pring = nullptr;
+  unsigned short* plds = nullptr;
+  unsigned char* pnb = nullptr;
+};
+// the DSS-on-read kernels of the whole-step path, as indices of tse_ctx::kshape
+enum { K_ADV1 = 0, K_LAP = 1, K_ADV2 = 2, K_DSS = 3 };
+
 struct tse_ctx {
   int nelemd = 0, qsize = 0, device = 0, rsplit = 3;
+  bool remap_alg2 = false;   // control_mod vert_remap_q_alg == 2: piecewise-constant boundary cells in the PPM remap
   double nu_q = 0, ps0 = 0;
   Dvv_t D;
   hipStream_t stream = nullptr;
@@ -54,7 +68,7 @@ struct tse_ctx {
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
   int* bad = nullptr;
-  int* pering = nullptr; unsigned char* pnb = nullptr;   // element ring / neighbour entries of the patches (stage-3 bounds)
+  int* bad_host = nullptr; hipEvent_t bad_ev[2] = {nullptr, nullptr};   // page-locked copies of `bad`, one per cycle in flight (tse_prim_run_subcycle)
   int mm_valid = 0;   // time level (1|2) whose element min/max of Q sit in qmin2/qmax2 (emitted by the previous step), 0 = none
   int mm_halo = 0;    // == mm_valid: the neighbour ranks' share of those bounds is already in recvbuf_mm (or on its way: ev_mm)
   hipEvent_t ev_mm = nullptr;   // completion of that prefetched exchange on the communication stream
@@ -73,10 +87,12 @@ struct tse_ctx {
   int *ord_bnd = nullptr, *ord_int = nullptr;
   int n_bnd = 0, n_int = 0;
   // element patches of the scratch layout (tse_kernels.h): slot = patch*16 + position
-  int npatch = 0, nslots = 0, np_bnd = 0, np_int = 0;
-  int *slot_of = nullptr, *pslots = nullptr, *plist_bnd = nullptr, *plist_int = nullptr;
-  unsigned* pring = nullptr;
-  unsigned short* plds = nullptr;
+  int nslots = 0;
+  int* slot_of = nullptr;
+  PatchSet pset[3];                        // patch tilings of 16, 24, 32 slots (4x4, 6x4, 8x4 elements); [0] is also the storage order
+  int kshape[4] = {16, 16, 16, 16};        // block shape of k_advance<1,1>, k_lap1<1>, k_advance<2,3>, k_dss_patch (patch_shape)
+  const PatchSet& set_of(int k) const { return pset[kshape[k] == 32 ? 2 : kshape[k] == 24 ? 1 : 0]; }
+  unsigned long long* pperm = nullptr;   // point order inside every slot of the scratch layout
   int2* send_src_s = nullptr;   // the send columns in slot space
   unsigned cse = 0;   // entries (points, halo columns) per chunk of a scratch plane
   bool halo() const { return ncol_send || ncol_recv; }
@@ -100,9 +116,10 @@ struct tse_ctx {
   Scr scr() const { return Scr{tps, cse}; }
   unsigned zero0() const { return (unsigned)nslots * 16; }          // entry index of the zero slot within a chunk
   unsigned halo0() const { return (unsigned)(nslots + 1) * 16; }    // entry index of halo column 0
-  GatherArgs gargs(const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
+  GatherArgs gargs(const PatchSet& P, const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
                    double* var_out = nullptr, int var_out_lev = 0) const {
-    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, pslots, pring, plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, nullptr, pering, pnb};
+    return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, P.pslots, P.pring, P.plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, nullptr,
+                      P.pering, P.pnb, pperm};
   }
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
@@ -172,6 +189,17 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   HIPCHK(hipGetDevice(&c->device));
   c->nelemd = a->nelemd; c->qsize = a->qsize; c->nu_q = a->nu_q; c->ps0 = a->ps0; c->rsplit = a->rsplit;
   c->exchange = a->exchange; c->exchange_user = a->exchange_user;
+  c->remap_alg2 = a->vert_remap_q_alg == 2;
+  {
+    // block shapes of the DSS-on-read kernels (measured defaults); TSE_PATCH_SHAPE="adv1,lap,adv2,dss" overrides them (A/B)
+    const char* e = getenv("TSE_PATCH_SHAPE");
+    int v[4] = {c->kshape[0], c->kshape[1], c->kshape[2], c->kshape[3]};
+    if (e && sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) != 4) return fail("tse_init: TSE_PATCH_SHAPE=\"%s\" (expected four of 16|24|32)", e);
+    for (int k = 0; k < 4; k++) {
+      if (v[k] != 16 && v[k] != 24 && v[k] != 32) return fail("tse_init: patch shape %d (16, 24 or 32 element slots)", v[k]);
+      c->kshape[k] = v[k];
+    }
+  }
   memcpy(c->D.d, a->Dvv, sizeof c->D.d);
   { std::vector<double> dv(a->Dvv, a->Dvv + 16); if (upload(&c->dvv_d, dv)) return 1; }
   HIPCHK(hipStreamCreate(&c->stream));
@@ -327,122 +355,176 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   }
 
   {
-    // Patches of the scratch layout: groups of <= 16 neighbouring elements (rows of up to 4 elements joined by their east links,
-    // up to 4 rows joined by the north link of each row's first element; no coordinates are needed and a patch may take any
-    // shape next to a cube seam or a rank boundary).  A DSS-on-read block owns one patch: what its slabs need from inside the
-    // patch travels through LDS, only the patch's halo ring comes from global memory.  Elements are taken in host order, so the
-    // patches of a full face tile it from its south-west corner.
-    std::vector<std::vector<int>> patches;
-    std::vector<int> pid(n, -1);
-    auto ring_size = [&](const std::vector<int>& cand, int me) {
-      std::vector<long> refs;
-      for (int e : cand)
-        for (int i = 0; i < 48; i++) {
-          const int2 t = tab[(size_t)e * 48 + i];
-          if (t.x == -1) continue;
-          if (t.x >= 0 && pid[t.x] == me) continue;                       // inside the candidate (marked below)
-          refs.push_back(t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1);
+    // Patches: groups of neighbouring elements -- rows of up to PW elements joined by their east links, up to 4 rows joined by
+    // the north link of each row's first element (no coordinates are needed and a patch may take any shape next to a cube seam or
+    // a rank boundary).  A DSS-on-read block owns one patch: what its slabs need from inside the patch travels through LDS, only
+    // the patch's halo ring comes from global memory.  Elements are taken in host order, so the patches of a full face tile it
+    // from its south-west corner.  The 4 x 4 tiling (set 0) is also the STORAGE order of the scratch fields (slot = patch * 16 +
+    // position); the wider shapes (6 x 4, 8 x 4: sets 1, 2) are built only for the kernels that were given them (patch_shape).
+    auto ring_key = [](const int2& t) { return t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1; };
+    auto build = [&](int psz, std::vector<std::vector<int>>& patches, std::vector<int>& pid) {
+      const int pw = psz / 4, nrmax = patch_nrmax(psz);
+      pid.assign(n, -1);
+      auto ring_size = [&](const std::vector<int>& cand, int me) {
+        std::vector<long> refs;
+        for (int e : cand)
+          for (int i = 0; i < 48; i++) {
+            const int2 t = tab[(size_t)e * 48 + i];
+            if (t.x == -1) continue;
+            if (t.x >= 0 && pid[t.x] == me) continue;                       // inside the candidate (marked below)
+            refs.push_back(ring_key(t));
+          }
+        std::sort(refs.begin(), refs.end());
+        return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
+      };
+      auto ering_size = [&](const std::vector<int>& cand, int me) {   // distinct elements (local or received) around the candidate
+        std::vector<long> refs;
+        for (int e : cand)
+          for (int d = 0; d < 8; d++) {
+            const int nb = nbr[e * 8 + d];
+            if (nb == -1 || (nb >= 0 && pid[nb] == me)) continue;
+            refs.push_back(nb);
+          }
+        std::sort(refs.begin(), refs.end());
+        return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
+      };
+      for (int seed = 0; seed < n; seed++) {
+        if (pid[seed] >= 0) continue;
+        const int me = (int)patches.size();
+        // fewer rows, then narrower rows, until the halo ring and the element ring fit the tables (one element always does)
+        for (int maxrows = 4, width = pw;; ) {
+          std::vector<int> cand;
+          int rowstart = seed;
+          for (int r = 0; r < maxrows && rowstart >= 0 && pid[rowstart] < 0; r++) {
+            int e = rowstart, cnt = 0;
+            const int first = e;
+            while (e >= 0 && pid[e] < 0 && cnt < width) { pid[e] = me; cand.push_back(e); cnt++; e = nbr[e * 8 + 1]; }   // east
+            rowstart = nbr[first * 8 + 3];                                                                             // north
+          }
+          if ((ring_size(cand, me) <= nrmax && ering_size(cand, me) <= NER) || (maxrows == 1 && width == 1)) { patches.push_back(cand); break; }
+          for (int e : cand) pid[e] = -1;
+          if (maxrows > 1) maxrows--; else width--;
         }
-      std::sort(refs.begin(), refs.end());
-      return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
-    };
-    auto ering_size = [&](const std::vector<int>& cand, int me) {   // distinct elements (local or received) around the candidate
-      std::vector<long> refs;
-      for (int e : cand)
-        for (int d = 0; d < 8; d++) {
-          const int nb = nbr[e * 8 + d];
-          if (nb == -1 || (nb >= 0 && pid[nb] == me)) continue;
-          refs.push_back(nb);
-        }
-      std::sort(refs.begin(), refs.end());
-      return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
-    };
-    for (int seed = 0; seed < n; seed++) {
-      if (pid[seed] >= 0) continue;
-      const int me = (int)patches.size();
-      for (int maxrows = 4; maxrows >= 1; maxrows--) {
-        std::vector<int> cand;
-        int rowstart = seed;
-        for (int r = 0; r < maxrows && rowstart >= 0 && pid[rowstart] < 0; r++) {
-          int e = rowstart, cnt = 0;
-          const int first = e;
-          while (e >= 0 && pid[e] < 0 && cnt < 4) { pid[e] = me; cand.push_back(e); cnt++; e = nbr[e * 8 + 1]; }   // east
-          rowstart = nbr[first * 8 + 3];                                                                         // north
-        }
-        if ((ring_size(cand, me) <= NRMAX && ering_size(cand, me) <= NER) || maxrows == 1) { patches.push_back(cand); break; }
-        for (int e : cand) pid[e] = -1;   // too long a halo ring for one load per lane: fewer rows
       }
-    }
-    c->npatch = (int)patches.size(); c->nslots = c->npatch * PS;
-    std::vector<int> slot_of(n, -1), pslots((size_t)c->nslots, -1);
-    for (int pi = 0; pi < c->npatch; pi++)
-      for (size_t i = 0; i < patches[pi].size(); i++) { slot_of[patches[pi][i]] = pi * PS + (int)i; pslots[(size_t)pi * PS + i] = patches[pi][i]; }
+    };
+    std::vector<std::vector<int>> patches[3];
+    std::vector<int> pid[3];
+    static const int shape_psz[3] = {16, 24, 32};
+    bool want[3] = {true, false, false};
+    for (int k = 0; k < 4; k++) for (int si = 0; si < 3; si++) if (c->kshape[k] == shape_psz[si]) want[si] = true;
+    for (int si = 0; si < 3; si++) if (want[si]) build(shape_psz[si], patches[si], pid[si]);
+    // ---- storage: the 4 x 4 tiling
+    c->nslots = (int)patches[0].size() * PS;
+    std::vector<int> slot_of(n, -1);
+    for (size_t pi = 0; pi < patches[0].size(); pi++)
+      for (size_t i = 0; i < patches[0][pi].size(); i++) slot_of[patches[0][pi][i]] = (int)pi * PS + (int)i;
     c->cse = (unsigned)(c->nslots + 1) * 16 + (unsigned)std::max(0, c->ncol_recv);
-    std::vector<unsigned> pring((size_t)c->npatch * NRMAX, c->zero0());
-    std::vector<unsigned short> plds((size_t)c->nslots * 48, (unsigned short)LDS_ZERO);
-    for (int pi = 0; pi < c->npatch; pi++) {
-      std::map<long, int> ring;   // source -> ring entry
-      for (size_t i = 0; i < patches[pi].size(); i++) {
-        const int e = patches[pi][i];
-        for (int k = 0; k < 48; k++) {
-          const int2 t = tab[(size_t)e * 48 + k];
-          unsigned short ent = (unsigned short)LDS_ZERO;
-          if (t.x >= 0 && pid[t.x] == pi) ent = (unsigned short)((slot_of[t.x] - pi * PS) * 16 + t.y);
-          else if (t.x != -1) {
-            const long key = t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1;
-            auto it = ring.find(key);
-            if (it == ring.end()) {
-              if ((int)ring.size() >= NRMAX) return fail("tse_init: halo ring of patch %d exceeds %d entries", pi, NRMAX);
-              it = ring.emplace(key, (int)ring.size()).first;
-              pring[(size_t)pi * NRMAX + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + ppos(t.y) : c->halo0() + (unsigned)(-(t.x + 2));
+    // Point order inside every slot (tse_kernels.h: ppos).  An edge of an element is READ FROM OUTSIDE when the neighbour across it
+    // belongs to another patch of some tiling in use (that patch's halo ring) or to another rank (the pack kernel); such an edge
+    // gets a 128-byte line of its own, in the order S, N, W, E.  An edge that shares a corner point with an edge placed before
+    // it (the corner elements of a patch export two edges) brings only its remaining points into a fresh line: it then costs
+    // its reader two lines.  The points nobody reads from outside fill what is left.
+    // TSE_AB_FIXED_PERM=1: the former fixed perimeter-first order (A/B).
+    std::vector<unsigned long long> pperm((size_t)c->nslots, 0x67895FEA4DCB3210ULL);
+    if (!(getenv("TSE_AB_FIXED_PERM") && atoi(getenv("TSE_AB_FIXED_PERM")))) {
+      static const int edge_dir[4] = {2, 3, 0, 1};   // S, N, W, E as direction indices (west, east, south, north = 0..3)
+      for (int e = 0; e < n; e++) {
+        int pos_of[16]; bool placed[16] = {false};
+        int line = 0;
+        for (int t = 0; t < 4; t++) {
+          const int d = edge_dir[t], nb = nbr[e * 8 + d];
+          bool outside = nb <= -2;
+          for (int si = 0; si < 3; si++) if (want[si] && nb >= 0 && pid[si][nb] != pid[si][e]) outside = true;
+          if (!outside) continue;
+          int cnt = 0;
+          for (int k = 0; k < 4; k++) { const int pt = edge_point(d, k); if (!placed[pt]) { placed[pt] = true; pos_of[pt] = line * 4 + cnt++; } }
+          if (cnt) line++;
+        }
+        bool used[16] = {false};
+        for (int pt = 0; pt < 16; pt++) if (placed[pt]) used[pos_of[pt]] = true;
+        int f = 0;
+        for (int pt = 0; pt < 16; pt++) if (!placed[pt]) { while (used[f]) f++; pos_of[pt] = f; used[f] = true; }
+        unsigned long long w = 0;
+        for (int pt = 0; pt < 16; pt++) w |= (unsigned long long)pos_of[pt] << (4 * pt);
+        pperm[slot_of[e]] = w;
+      }
+    }
+    const bool ab_noring = getenv("TSE_AB_NORING") && atoi(getenv("TSE_AB_NORING"));   // A/B: no halo-ring loads at all (WRONG results; bounds what the ring costs)
+    std::vector<char> isb(n, 0);   // elements that touch another rank
+    for (const int2& q : send_src) isb[q.x] = 1;
+    for (const int2& q : mm_src) isb[q.x] = 1;
+    // ---- the tables of every tiling in use
+    for (int si = 0; si < 3; si++) {
+      if (!want[si]) continue;
+      PatchSet& P = c->pset[si];
+      const int psz = shape_psz[si], nrmax = patch_nrmax(psz);
+      const std::vector<std::vector<int>>& pt = patches[si];
+      P.psz = psz; P.npatch = (int)pt.size();
+      const size_t nts = (size_t)P.npatch * psz;   // table slots
+      std::vector<int> pslots(nts, -1), tslot_of(n, -1);
+      for (int pi = 0; pi < P.npatch; pi++)
+        for (size_t i = 0; i < pt[pi].size(); i++) { pslots[(size_t)pi * psz + i] = pt[pi][i]; tslot_of[pt[pi][i]] = pi * psz + (int)i; }
+      std::vector<unsigned> pring((size_t)P.npatch * nrmax, c->zero0());
+      std::vector<unsigned short> plds(nts * 48, (unsigned short)(psz * 16 + nrmax));   // LDS_ZERO of the shape
+      for (int pi = 0; pi < P.npatch; pi++) {
+        std::map<long, int> ring;   // source -> ring entry
+        for (size_t i = 0; i < pt[pi].size(); i++) {
+          const int e = pt[pi][i];
+          for (int k = 0; k < 48; k++) {
+            const int2 t = tab[(size_t)e * 48 + k];
+            unsigned short ent = (unsigned short)(psz * 16 + nrmax);
+            if (t.x >= 0 && pid[si][t.x] == pi) ent = (unsigned short)((tslot_of[t.x] - pi * psz) * 16 + t.y);
+            else if (t.x != -1) {
+              const long key = ring_key(t);
+              auto it = ring.find(key);
+              if (it == ring.end()) {
+                if ((int)ring.size() >= nrmax) return fail("tse_init: halo ring of patch %d exceeds %d entries", pi, nrmax);
+                it = ring.emplace(key, (int)ring.size()).first;
+                if (!ab_noring)
+                  pring[(size_t)pi * nrmax + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + ppos(pperm[slot_of[t.x]], t.y) : c->halo0() + (unsigned)(-(t.x + 2));
+              }
+              ent = (unsigned short)(psz * 16 + it->second);
             }
-            ent = (unsigned short)(PS * 16 + it->second);
+            plds[((size_t)pi * psz + i) * 48 + k] = ent;
           }
-          plds[((size_t)pi * PS + i) * 48 + k] = ent;
         }
       }
-    }
-    // element ring and neighbour entries of every patch, for the bounds image of the stage-3 kernel (k_advance<2,3>)
-    std::vector<int> pering((size_t)c->npatch * NER, 0);
-    std::vector<unsigned char> pnb((size_t)c->nslots * 8, 255);
-    for (int pi = 0; pi < c->npatch; pi++) {
-      std::map<int, int> ring;   // element (or -(received entry) - 2) -> ring entry
-      for (int r = 0; r < NER; r++) pering[(size_t)pi * NER + r] = patches[pi][0];   // unused entries: any valid element
-      for (size_t i = 0; i < patches[pi].size(); i++) {
-        const int e = patches[pi][i];
-        for (int d = 0; d < 8; d++) {
-          const int nb = nbr[e * 8 + d];
-          if (nb == -1) continue;
-          if (nb >= 0 && pid[nb] == pi) { pnb[((size_t)pi * PS + i) * 8 + d] = (unsigned char)(slot_of[nb] - pi * PS); continue; }
-          auto it = ring.find(nb);
-          if (it == ring.end()) {
-            if ((int)ring.size() >= NER) return fail("tse_init: patch %d has more than %d elements around it", pi, NER);
-            it = ring.emplace(nb, (int)ring.size()).first;
-            pering[(size_t)pi * NER + it->second] = nb >= 0 ? nb : n + (-(nb + 2));
+      // element ring and neighbour entries of every patch, for the bounds image of the stage-3 kernel (k_advance<2,3>)
+      std::vector<int> pering((size_t)P.npatch * NER, 0);
+      std::vector<unsigned char> pnb(nts * 8, 255);
+      for (int pi = 0; pi < P.npatch; pi++) {
+        std::map<int, int> ring;   // element (or -(received entry) - 2) -> ring entry
+        for (int r = 0; r < NER; r++) pering[(size_t)pi * NER + r] = pt[pi][0];   // unused entries: any valid element
+        for (size_t i = 0; i < pt[pi].size(); i++) {
+          const int e = pt[pi][i];
+          for (int d = 0; d < 8; d++) {
+            const int nb = nbr[e * 8 + d];
+            if (nb == -1) continue;
+            if (nb >= 0 && pid[si][nb] == pi) { pnb[((size_t)pi * psz + i) * 8 + d] = (unsigned char)(tslot_of[nb] - pi * psz); continue; }
+            auto it = ring.find(nb);
+            if (it == ring.end()) {
+              if ((int)ring.size() >= NER) return fail("tse_init: patch %d has more than %d elements around it", pi, NER);
+              it = ring.emplace(nb, (int)ring.size()).first;
+              pering[(size_t)pi * NER + it->second] = nb >= 0 ? nb : n + (-(nb + 2));
+            }
+            pnb[((size_t)pi * psz + i) * 8 + d] = (unsigned char)(psz + it->second);
           }
-          pnb[((size_t)pi * PS + i) * 8 + d] = (unsigned char)(PS + it->second);
         }
       }
-    }
-    if (upload(&c->pering, pering) || upload(&c->pnb, pnb)) return 1;
-    std::vector<int2> send_s(send_src);
-    for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(t.y); }   // {slot, position within the slot}
-    // rank-boundary patches first, as the elements above
-    std::vector<int> pb, pin;
-    {
-      std::vector<int> ob;   // (host copy of ord_bnd)
-      std::vector<char> isb(n, 0);
-      for (const int2& q : send_src) isb[q.x] = 1;
-      for (const int2& q : mm_src) isb[q.x] = 1;
-      for (int pi = 0; pi < c->npatch; pi++) {
+      // rank-boundary patches first, as the elements above
+      std::vector<int> pb, pin;
+      for (int pi = 0; pi < P.npatch; pi++) {
         bool b = false;
-        for (int e : patches[pi]) b = b || isb[e];
+        for (int e : pt[pi]) b = b || isb[e];
         (b ? pb : pin).push_back(pi);
       }
+      P.np_bnd = (int)pb.size(); P.np_int = (int)pin.size();
+      if (upload(&P.pslots, pslots) || upload(&P.pring, pring) || upload(&P.plds, plds) || upload(&P.pering, pering) || upload(&P.pnb, pnb) ||
+          upload(&P.plist_bnd, pb) || upload(&P.plist_int, pin)) return 1;
     }
-    c->np_bnd = (int)pb.size(); c->np_int = (int)pin.size();
-    if (upload(&c->slot_of, slot_of) || upload(&c->pslots, pslots) || upload(&c->pring, pring) || upload(&c->plds, plds) ||
-        upload(&c->send_src_s, send_s) || upload(&c->plist_bnd, pb) || upload(&c->plist_int, pin)) return 1;
+    std::vector<int2> send_s(send_src);
+    for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(pperm[t.x], t.y); }   // {slot, position within the slot}
+    if (upload(&c->slot_of, slot_of) || upload(&c->send_src_s, send_s) || upload(&c->pperm, pperm)) return 1;
   }
 
   // ---- state -------------------------------------------------------------------------------------
@@ -467,6 +549,9 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
   HIPCHK(hipMemset(c->qmin, 0, mm * 8)); HIPCHK(hipMemset(c->qmax, 0, mm * 8));
   HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&c->bad_host, 2 * sizeof(int), hipHostMallocDefault));
+  c->bad_host[0] = c->bad_host[1] = 0;
+  for (hipEvent_t& e : c->bad_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   // Halo buffers.  The reference sizes one aliased buffer for 3*qsize*nlev layers (prim_advection_mod.F90:488); here the
   // tracer DSS (qsize*nlev + nlev layers per column) and the element-constant min/max exchange (2*qsize*nlev per
   // (element, direction) pair) have their own buffers, so that the two exchanges of stage 3 can be in flight together.
@@ -482,8 +567,10 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     for (hipEvent_t& e : c->sync_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
   }
-  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
-  HIPCHK(hipFuncSetAttribute((const void*)k_remap<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipDeviceSynchronize());
   return 0;
 }
@@ -493,6 +580,8 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
   *out = nullptr;
   if (a->limiter_option != 8) return fail("tse_init: only limiter_option=8 is supported (got %d)", a->limiter_option);
   if (a->nelemd <= 0 || a->qsize <= 0) return fail("tse_init: nelemd=%d qsize=%d", a->nelemd, a->qsize);
+  if (a->vert_remap_q_alg < 0 || a->vert_remap_q_alg > 2)
+    return fail("tse_init: vert_remap_q_alg=%d (0|1: mirrored ghost cells, 2: piecewise-constant boundary cells; control_mod.F90:61-66)", a->vert_remap_q_alg);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("tse_init: no HIP device (this library has no CPU fallback)");
   tse_ctx* c = new tse_ctx();
@@ -511,13 +600,18 @@ void tse_finalize(tse_ctx* c) {
   if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
   if (c->pin_hi) (void)hipHostUnregister((void*)c->pin_lo);
+  if (c->bad_host) (void)hipHostFree(c->bad_host);
+  for (hipEvent_t e : c->bad_ev) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
-                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->pslots, c->plist_bnd,
-                  c->plist_int, c->pring, c->plds, c->send_src_s, c->pering, c->pnb};
+                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (PatchSet& P : c->pset) {
+    void* tp[] = {P.pslots, P.plist_bnd, P.plist_int, P.pering, P.pring, P.plds, P.pnb};
+    for (void* p : tp) if (p) (void)hipFree(p);
+  }
   resolve_timers(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->sync_events) if (e) (void)hipEventDestroy(e);
@@ -543,6 +637,15 @@ int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; 
 int tse_invalidate_cache(tse_ctx* c) { set_bounds_cache(c, 0); c->dcmip_static = false; return 0; }
 
 // ---- RCCL communicator ----------------------------------------------------------------------------
+static const char* rccl_path() {
+  static char buf[512] = "";
+  if (!buf[0]) {
+    Dl_info info;
+    if (dladdr((void*)&ncclGetVersion, &info) && info.dli_fname) strncpy(buf, info.dli_fname, sizeof buf - 1);
+    else strcpy(buf, "?");
+  }
+  return buf;
+}
 int tse_comm_unique_id(void* id_out) {
   static_assert(sizeof(ncclUniqueId) == TSE_COMM_ID_BYTES, "ncclUniqueId size");
   if (!id_out) return fail("tse_comm_unique_id: null argument");
@@ -551,18 +654,50 @@ int tse_comm_unique_id(void* id_out) {
   memcpy(id_out, &id, sizeof id);
   return 0;
 }
+// Everything tse_comm_init can find wrong WITHOUT talking to the other ranks.  ncclCommInitRank is a blocking collective: a rank
+// that returned early from tse_comm_init would leave its peers inside the bootstrap for ever, so a host first calls this on
+// every rank, agrees on the outcome over its own control plane (MPI_Allreduce, a gloo all_gather), and enters tse_comm_init
+// only if every rank is ready (driver.PrimRun, cuda_mod_hip.F90).
+int tse_comm_precheck(tse_ctx* c, int rank, int nranks) {
+  if (!c) return fail("tse_comm_precheck: null context");
+  if (c->comm) return fail("tse_comm_precheck: communicator already initialised");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail("tse_comm_precheck: rank %d of %d", rank, nranks);
+  for (int p : c->send_peer) if (p < 0 || p >= nranks) return fail("tse_comm_precheck: send peer %d (this is rank %d of %d)", p, rank, nranks);
+  for (int p : c->recv_peer) if (p < 0 || p >= nranks) return fail("tse_comm_precheck: recv peer %d (this is rank %d of %d)", p, rank, nranks);
+  if (getenv("TSE_TEST_FAIL_PRECHECK_RANK") && atoi(getenv("TSE_TEST_FAIL_PRECHECK_RANK")) == rank)   // tests: one rank alone is not ready
+    return fail("tse_comm_precheck: rank %d fails on request (TSE_TEST_FAIL_PRECHECK_RANK)", rank);
+  if (c->halo() && !c->comm_stream) return fail("tse_comm_precheck: no communication stream");
+  HIPCHK(hipSetDevice(c->device));
+  int rt = 0;
+  NCCLCHK(ncclGetVersion(&rt));
+  // The library was compiled against rccl.h NCCL_MAJOR.NCCL_MINOR.NCCL_PATCH; the process runs whichever librccl.so.1 was loaded
+  // first (under Python: the copy bundled with torch, see _lib.py -- one RCCL per process).  The seven entry points used here
+  // (ncclGetUniqueId, ncclCommInitRank, ncclGroupStart/End, ncclSend, ncclRecv, ncclCommAbort/Destroy) have kept their
+  // signatures through all of 2.x, so a different minor is accepted and REPORTED (tse_comm_version); another major, or a
+  // runtime older than point-to-point send/recv (2.7), is refused.
+  if (rt / 10000 != NCCL_MAJOR || rt < 20700)
+    return fail("tse_comm_precheck: RCCL runtime %d.%d.%d (%s) cannot serve a library built with the headers of %d.%d.%d", rt / 10000, rt / 100 % 100,
+                rt % 100, rccl_path(), NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+  return 0;
+}
 int tse_comm_init(tse_ctx* c, const void* id_in, int rank, int nranks) {
   if (!c || !id_in) return fail("tse_comm_init: null argument");
-  if (c->comm) return fail("tse_comm_init: communicator already initialised");
-  if (rank < 0 || rank >= nranks) return fail("tse_comm_init: rank %d of %d", rank, nranks);
-  for (int p : c->send_peer) if (p < 0 || p >= nranks) return fail("tse_comm_init: send peer %d outside the %d-rank communicator", p, nranks);
-  for (int p : c->recv_peer) if (p < 0 || p >= nranks) return fail("tse_comm_init: recv peer %d outside the %d-rank communicator", p, nranks);
-  HIPCHK(hipSetDevice(c->device));
+  if (tse_comm_precheck(c, rank, nranks)) return 1;
   ncclUniqueId id;
   memcpy(&id, id_in, sizeof id);
   ncclComm_t cm = nullptr;
   NCCLCHK(ncclCommInitRank(&cm, nranks, id, rank));   // on failure the context keeps its callback route (c->comm stays null)
   c->comm = cm;
+  return 0;
+}
+// which RCCL this process resolved: version code of the runtime (ncclGetVersion), of the headers the library was built with, and
+// the path of the shared object that provides ncclGetVersion (dladdr)
+int tse_comm_version(int* runtime, int* built, char* path, size_t path_len) {
+  int rt = 0;
+  NCCLCHK(ncclGetVersion(&rt));
+  if (runtime) *runtime = rt;
+  if (built) *built = NCCL_VERSION_CODE;
+  if (path && path_len) { strncpy(path, rccl_path(), path_len - 1); path[path_len - 1] = 0; }
   return 0;
 }
 int tse_comm_abort(tse_ctx* c) {
@@ -815,8 +950,8 @@ static int nbr_minmax_kernel(tse_ctx* c) {
   const int m = c->qsize * NLEV;
   {
     Scope s(c, "minmax");
-    hipLaunchKernelGGL(k_nbr_minmax_patch<8>, dim3(nbr_patch_blocks(c->npatch, c->qsize)), dim3(512), 0, c->stream, c->npatch, c->qsize, c->nbr,
-                       c->pslots, c->slot_of, c->qmin, c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m);
+    hipLaunchKernelGGL(k_nbr_minmax_patch<8>, dim3(nbr_patch_blocks(c->pset[0].npatch, c->qsize)), dim3(512), 0, c->stream, c->pset[0].npatch, c->qsize, c->nbr,
+                       c->pset[0].pslots, c->slot_of, c->qmin, c->qmax, c->qmin2, c->qmax2, c->recvbuf_mm, 2 * m);
     LAUNCH_CHECK();
   }
   std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
@@ -845,22 +980,34 @@ static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
 }
 // tracer DSS pass src (scratch layout, halo columns filled) -> dst (standard layout), optionally fused with qdp_time_avg and the
 // next step's bounds; over all patches (npwork < 0) or over the patch list of a split launch
+// run f(std::integral_constant<int, PSZ>) for the block shape psz
+template <class F>
+static int with_shape(int psz, F f) {
+  if (psz == 32) return f(std::integral_constant<int, 32>{});
+  if (psz == 24) return f(std::integral_constant<int, 24>{});
+  return f(std::integral_constant<int, 16>{});
+}
 static int dss_tracer_launch(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, const int* plist, int npwork,
                              double* var_out = nullptr, int var_out_lev = 0) {
   if (!npwork) return 0;
-  const GatherArgs ga = c->gargs(nullptr, c->nelemd, plist, npwork, nullptr, 0, var_out, var_out_lev);
-  const dim3 grid(patch_blocks(npwork)), blk(FLAT_THREADS);
-  if (Qn0_avg)
-    hipLaunchKernelGGL(k_dss_patch<1>, grid, blk, 0, c->stream, c->qsize, src, dst, Qn0_avg, (const double*)c->dp, c->qmin2, c->qmax2, ga);
-  else
-    hipLaunchKernelGGL(k_dss_patch<0>, grid, blk, 0, c->stream, c->qsize, src, dst, (const double*)nullptr, (const double*)nullptr,
-                       (double*)nullptr, (double*)nullptr, ga);
+  const PatchSet& P = c->set_of(K_DSS);
+  const GatherArgs ga = c->gargs(P, nullptr, c->nelemd, plist, npwork, nullptr, 0, var_out, var_out_lev);
+  const dim3 grid(patch_blocks(npwork));
+  with_shape(P.psz, [&](auto psz) {
+    constexpr int Z = decltype(psz)::value;
+    if (Qn0_avg)
+      hipLaunchKernelGGL((k_dss_patch<1, Z>), grid, dim3(Patch<Z>::THREADS), 0, c->stream, c->qsize, src, dst, Qn0_avg, (const double*)c->dp, c->qmin2, c->qmax2, ga);
+    else
+      hipLaunchKernelGGL((k_dss_patch<0, Z>), grid, dim3(Patch<Z>::THREADS), 0, c->stream, c->qsize, src, dst, (const double*)nullptr, (const double*)nullptr,
+                         (double*)nullptr, (double*)nullptr, ga);
+    return 0;
+  });
   LAUNCH_CHECK();
   return 0;
 }
 static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const double* Qn0_avg, double* var_out = nullptr, int var_out_lev = 0) {
   Scope s(c, "dss");
-  return dss_tracer_launch(c, src, dst, Qn0_avg, nullptr, c->npatch, var_out, var_out_lev);
+  return dss_tracer_launch(c, src, dst, Qn0_avg, nullptr, c->set_of(K_DSS).npatch, var_out, var_out_lev);
 }
 
 // One euler_step of the per-stage API (prim_advection_mod.F90:667-970): every stage ends with a tracer DSS pass, because
@@ -874,7 +1021,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
   const int nq = c->qsize * NLEV;
   const dim3 grid(flat_blocks(c->nelemd)), blk(FLAT_THREADS);
-  const GatherArgs plain = c->gargs(nullptr, c->nelemd, nullptr, 0);
+  const GatherArgs plain = c->gargs(c->pset[0], nullptr, c->nelemd, nullptr, 0);
   if (rhs == 0) {
     if (fused_mm && c->mm_valid == n0_qdp) {
       // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
@@ -957,26 +1104,27 @@ static hipEvent_t next_sync_event(tse_ctx* c) {
 }
 
 // the part of the local mesh one launch covers: everything (single rank), the elements / patches that touch another rank, the rest
-struct Work { const int* order; int nwork; const int* plist; int npwork; };
-static Work work_of(const tse_ctx* c, int part) {
-  if (part == 0) return Work{nullptr, c->nelemd, nullptr, c->npatch};
-  if (part == 1) return Work{c->ord_bnd, c->n_bnd, c->plist_bnd, c->np_bnd};
-  return Work{c->ord_int, c->n_int, c->plist_int, c->np_int};
+struct Work { const int* order; int nwork; const PatchSet* P; const int* plist; int npwork; };
+static Work work_of(const tse_ctx* c, int part, int kidx) {
+  const PatchSet& P = c->set_of(kidx);
+  if (part == 0) return Work{nullptr, c->nelemd, &P, nullptr, P.npatch};
+  if (part == 1) return Work{c->ord_bnd, c->n_bnd, &P, P.plist_bnd, P.np_bnd};
+  return Work{c->ord_int, c->n_int, &P, P.plist_int, P.np_int};
 }
 
 // done_out == nullptr: the compute stream waits for the communication work before it goes on; otherwise the event that marks
 // its completion is handed back and whoever consumes the halo waits for it (the prefetched bounds exchange)
 template <class Launch, class CommWork>
-static int split_stage(tse_ctx* c, const char* timer, Launch launch /* (Work) */, CommWork comm_work /* () on c->comm_stream */,
-                       hipEvent_t* done_out = nullptr) {
+static int split_stage(tse_ctx* c, const char* timer, int kidx /* whose patch tiling the launches walk */, Launch launch /* (Work) */,
+                       CommWork comm_work /* () on c->comm_stream */, hipEvent_t* done_out = nullptr) {
   Scope s(c, timer);
-  if (!c->halo()) return launch(work_of(c, 0));
-  if (launch(work_of(c, 1))) return 1;
+  if (!c->halo()) return launch(work_of(c, 0, kidx));
+  if (launch(work_of(c, 1, kidx))) return 1;
   hipEvent_t evB = next_sync_event(c), evC = done_out ? c->ev_mm : next_sync_event(c);
   HIPCHK(hipEventRecord(evB, c->stream));
   HIPCHK(hipStreamWaitEvent(c->comm_stream, evB, 0));
   if (c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
-  if (launch(work_of(c, 2))) return 1;
+  if (launch(work_of(c, 2, kidx))) return 1;
   if (!c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
   if (done_out) *done_out = evC;
   else HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
@@ -994,7 +1142,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   // the stage's extra DSS variable travels as plane qsize of the stage's scratch output and is assembled on read by the next
   // kernel (var_in / var_out of GatherArgs): divdp_proj with stage 1, eta_dot_dpdn with stage 2, omega_p with stage 3
   auto gargs = [&](const Work& w, const double* vin = nullptr, int vin_lev = 0, double* vout = nullptr, int vout_lev = 0) {
-    return c->gargs(w.order, w.nwork, w.plist, w.npwork, vin, vin_lev, vout, vout_lev);
+    return c->gargs(*w.P, w.order, w.nwork, w.plist, w.npwork, vin, vin_lev, vout, vout_lev);
   };
   const int nqv = nq + NLEV;   // layers of a tracer halo message with the extra variable behind the tracers
 
@@ -1021,7 +1169,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
   }
   if (nbr_minmax_kernel(c)) return 1;
-  if (split_stage(c, "advance0",
+  if (split_stage(c, "advance0", K_ADV1,
         [&](Work w) -> int {
           if (!w.nwork) return 0;
           GatherArgs ga = gargs(w, c->divdp_proj, NLEV);
@@ -1032,39 +1180,49 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
         [&]() -> int { return pack_tracers(c, cs, c->T, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->T, nqv, nqv); })) return 1;
 
   // ---- stage 2 (rhs_multiplier 1, DSS extra = eta_dot_dpdn): T (+) edges -> B
-  if (split_stage(c, "advance1",
+  if (split_stage(c, "advance1", K_ADV1,
         [&](Work w) -> int {
           if (!w.npwork) return 0;
-          hipLaunchKernelGGL((k_advance<1, 1>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->T,
-                             (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                             gargs(w, c->eta, NLEVP, c->divdp_proj, NLEV));
+          with_shape(w.P->psz, [&](auto psz) {
+            constexpr int Z = decltype(psz)::value;
+            hipLaunchKernelGGL((k_advance<1, 1, true, Z>), dim3(patch_blocks(w.npwork)), dim3(Patch<Z>::THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts,
+                               c->nu_q, (const double*)c->T, (const double*)nullptr, c->B, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                               gargs(w, c->eta, NLEVP, c->divdp_proj, NLEV));
+            return 0; });
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->B, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->B, nqv, nqv); })) return 1;
 
   // ---- stage 3 (rhs_multiplier 2, DSS extra = omega_p)
   // 3a: B (+) edges -> first Laplacian (pre-DSS) of the stage-2 tracers in T, element min/max (the DSS'd tracers themselves are
   //     not stored: 3b assembles them again from B); the element bounds and the Laplacian halo travel together (biharmonic_wk_scalar_minmax packs lap, Qmin, Qmax into one message: viscosity_mod.F90:389-391)
-  if (split_stage(c, "lap",
+  if (split_stage(c, "lap", K_LAP,
         [&](Work w) -> int {
           if (!w.npwork) return 0;
-          hipLaunchKernelGGL(k_lap1<1>, dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts, (const double*)c->B, c->T, c->dp,
-                             c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
+          with_shape(w.P->psz, [&](auto psz) {
+            constexpr int Z = decltype(psz)::value;
+            hipLaunchKernelGGL((k_lap1<1, Z>), dim3(patch_blocks(w.npwork)), dim3(Patch<Z>::THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts,
+                               (const double*)c->B, c->T, c->dp, c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
+            return 0; });
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || unpack_minmax(c, cs) || pack_tracers(c, cs, c->T, nq) ||
                               halo_exchange(c, nq, 0, cs) || unpack_halo(c, cs, c->T, nq); })) return 1;
   // (no neighbour min/max pass here: 3b forms it from the element bounds -- its patch's and the element ring's -- while it runs)
   // 3b: B (+) edges, T (+) edges -> C (2nd Laplacian + biharmonic scaling + advance + limiter)
-  if (split_stage(c, "advance2",
+  if (split_stage(c, "advance2", K_ADV2,
         [&](Work w) -> int {
           if (!w.npwork) return 0;
-          hipLaunchKernelGGL((k_advance<2, 3>), dim3(patch_blocks(w.npwork)), blk, 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, (const double*)c->B,
-                             (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w, c->omega_p, NLEV));
+          with_shape(w.P->psz, [&](auto psz) {
+            constexpr int Z = decltype(psz)::value;
+            hipLaunchKernelGGL((k_advance<2, 3, true, Z>), dim3(patch_blocks(w.npwork)), dim3(Patch<Z>::THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts,
+                               c->nu_q, (const double*)c->B, (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
+                               gargs(w, c->omega_p, NLEV));
+            return 0; });
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->C, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->C, nqv, nqv); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
   if (prefetch && c->halo()) {
     hipEvent_t done = nullptr;
-    if (split_stage(c, "dss",
+    if (split_stage(c, "dss", K_DSS,
           [&](Work w) -> int { return dss_tracer_launch(c, c->C, Qnp1, Qn0, w.plist, w.npwork, c->omega_p, NLEV); },
           [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done)) return 1;
     set_bounds_cache(c, np1_qdp);
@@ -1117,12 +1275,12 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
   double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
   auto launch = [&](Work w) -> int {   // block = element
     if (!w.nwork) return 0;
-    if (nt == 1)
-      hipLaunchKernelGGL(k_remap<1>, dim3(w.nwork), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+    auto go = [&](auto kern, int threads) {
+      hipLaunchKernelGGL(kern, dim3(w.nwork), dim3(threads), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
                          c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order);
-    else
-      hipLaunchKernelGGL(k_remap<2>, dim3(w.nwork), dim3(REMAP_THREADS / 2), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order);
+    };
+    if (nt == 1) { if (c->remap_alg2) go(k_remap<1, true>, REMAP_THREADS); else go(k_remap<1, false>, REMAP_THREADS); }
+    else { if (c->remap_alg2) go(k_remap<2, true>, REMAP_THREADS / 2); else go(k_remap<2, false>, REMAP_THREADS / 2); }
     LAUNCH_CHECK();
     return 0;
   };
@@ -1130,13 +1288,13 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
     const int nq = c->qsize * NLEV;
     hipStream_t cs = c->comm_stream;
     hipEvent_t done = nullptr;
-    if (split_stage(c, "remap", launch, [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done))
+    if (split_stage(c, "remap", K_DSS, launch, [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done))
       return 1;
     set_bounds_cache(c, np1_qdp);   // k_remap emitted the element min/max of the remapped field
     c->mm_halo = np1_qdp;
   } else {
     Scope s(c, "remap");
-    if (launch(work_of(c, 0))) return 1;
+    if (launch(work_of(c, 0, K_DSS))) return 1;
     set_bounds_cache(c, np1_qdp);
   }
   return 0;
@@ -1185,6 +1343,7 @@ int tse_laplace_sphere_wk(tse_ctx* c, const double* s, double* lap) { return ele
 int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp2) {
   if (!Qdp || !dp1 || !dp2) return fail("tse_remap_q_ppm: null argument");
   set_bounds_cache(c, 0);
+  c->dcmip_static = false;   // dp is overwritten below: the next tse_dcmip_step_inputs must write the prescribed values again
   const size_t lev = c->lev();
   double* d2 = nullptr;
   if (dalloc(&d2, lev)) return 1;
@@ -1193,9 +1352,12 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
     if (hipMemcpy(c->qdp, Qdp, c->trc() * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->dp, dp1, lev * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d2, dp2, lev * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->divdp_proj, 0, lev * 8) != hipSuccess) { rc = fail("tse_remap_q_ppm: upload failed"); break; }
     const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
-    hipLaunchKernelGGL(k_remap<1>, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
-                       c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
-                       (const int*)nullptr);
+    auto go = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
+                         (const int*)nullptr);
+    };
+    if (c->remap_alg2) go(k_remap<1, true>); else go(k_remap<1, false>);
     if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(Qdp, c->qdp, c->trc() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("tse_remap_q_ppm: download failed"); break; }
     rc = remap_check(c);
@@ -1268,8 +1430,26 @@ int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
   return 0;
 }
 int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
-  int nstep = *nstep_io;
+  const int nstep0 = *nstep_io;
+  int nstep = nstep0;
+  // The reference aborts in the first remap that meets a negative layer thickness (prim_advection_mod.F90:1323).  Here the
+  // device flag is copied to page-locked memory behind every cycle's remap and looked at TWO cycles later -- by then the copy
+  // has long landed, so the host never waits for the device while it keeps a full cycle queued ahead -- and the call returns 2
+  // with *nstep = the step count at the end of the failing cycle (at most two more cycles were started on the bad state).
+  // (With the callback form of the halo exchange every stage synchronises with the host anyway.)
+  auto failed = [&](int cyc) -> int {
+    *nstep_io = nstep0 + (cyc + 1) * c->rsplit;
+    set_bounds_cache(c, 0);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemset(c->bad, 0, sizeof(int));
+    fail("negative layer thickness.  timestep or remap time too large");
+    return 2;
+  };
   for (int s = 0; s < nsub; s++) {
+    if (s >= 2) {
+      HIPCHK(hipEventSynchronize(c->bad_ev[s & 1]));
+      if (c->bad_host[s & 1]) return failed(s - 2);
+    }
     int n0 = 1, np1 = 2;
     for (int r = 0; r < c->rsplit; r++) {
       if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
@@ -1278,10 +1458,15 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
       nstep++;
     }
     if (remap_launch(c, tstep * c->rsplit, np1, true)) { *nstep_io = nstep; return 1; }
+    HIPCHK(hipMemcpyAsync(&c->bad_host[s & 1], c->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipEventRecord(c->bad_ev[s & 1], c->stream));
   }
   *nstep_io = nstep;
-  // the negative-thickness flag of all nsub remaps is read once: the loop above never blocks the host
-  return remap_check(c);
+  for (int s = std::max(0, nsub - 2); s < nsub; s++) {
+    HIPCHK(hipEventSynchronize(c->bad_ev[s & 1]));
+    if (c->bad_host[s & 1]) return failed(s);
+  }
+  return 0;
 }
 
 // ---- introspection ------------------------------------------------------------------------------

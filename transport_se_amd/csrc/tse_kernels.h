@@ -30,18 +30,29 @@ constexpr int FLAT_THREADS = 256;
 constexpr int CL = 4;
 constexpr int NCHUNK = NLEV / CL;
 static_assert(NLEV % CL == 0 && CL % 2 == 0, "chunks hold whole level pairs");
-constexpr int PS = 16;        // element slots per patch
-constexpr int NRMAX = 128;    // halo-ring entries of a patch (a full 4x4 patch has 92; tse_api.hip splits patches that need more)
+constexpr int PS = 16;        // element slots per patch of the STORAGE tiling (4 x 4 elements): slot = patch * PS + position
+// Block shapes of the DSS-on-read kernels.  A block owns a patch of PSZ element slots -- 4 x 4, 6 x 4 or 8 x 4 elements: 256, 384 or
+// 512 lanes -- whatever the storage tiling is: its tables (PatchSet, tse_api.hip) name the storage slot of every element and of
+// every halo-ring entry.  A wider patch has a shorter ring per element (0.375, 0.29, 0.25 of a field in whole lines), a narrower
+// one leaves room for more blocks per CU; each kernel takes the shape that suits its register and LDS budget.
+template <int PSZ> struct Patch {
+  static_assert(PSZ == 16 || PSZ == 24 || PSZ == 32, "patch shapes: 4x4, 6x4, 8x4 elements");
+  static constexpr int PS = PSZ, THREADS = PSZ * 16;
+  // halo-ring entries (distinct (element, point) pairs outside the patch: 68, 84, 100 for the full shapes; tse_api.hip gives a
+  // patch fewer rows if its ring would not fit); lanes 2r, 2r+1 load entry r
+  static constexpr int NRMAX = PSZ == 16 ? 96 : PSZ == 24 ? 112 : 128;
+  static constexpr int LDS_ZERO = PSZ * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
+  static_assert(2 * NRMAX <= THREADS, "one 16-byte ring load per lane");
+};
+inline int patch_nrmax(int psz) { return psz == 16 ? Patch<16>::NRMAX : psz == 24 ? Patch<24>::NRMAX : Patch<32>::NRMAX; }
 struct Scr { size_t tps; unsigned cse; };   // plane stride (doubles), entries per chunk
-// Inside a slot the 16 points are stored perimeter first -- S edge (points 0,1,2,3), E (7,11,15), N (14,13,12), W (8,4), then the
-// interior (5,6,9,10) -- so that the 4 points of an edge, which is what a neighbouring patch's halo ring reads, are 128
-// contiguous bytes (1-2 lines) instead of 32 bytes out of each of 4 lines.  PPOS: nibble p = position of point p.
-constexpr unsigned long long PPOS = 0x67895FEA4DCB3210ULL;
-__host__ __device__ __forceinline__ int ppos(int p) { return (int)((PPOS >> (4 * p)) & 15ull); }
-// element index of T[q][k / CL][slot][pos][k % CL], pos = ppos(point)
-__device__ __forceinline__ size_t t_idx(Scr S, int q, int slot, int pos, int k) {
-  return (size_t)q * S.tps + ((size_t)(k / CL) * S.cse + (size_t)slot * 16 + pos) * CL + (k % CL);
-}
+// Inside a slot the 16 points are stored in a PER-SLOT order (nibble p of the slot's 64-bit word pperm[slot] = position of
+// point p).  The memory system moves whole 128-byte lines (tools/fetch_probe.hip: 32 bytes out of every line cost what the
+// line costs), a position holds the CL = 4 levels of a point = 32 bytes, so a slot is four lines of four points -- and what a
+// neighbouring patch's halo ring reads from a slot is one EDGE of the element (4 points).  tse_init gives every edge that
+// some patch or neighbour rank reads a line of its own (slot_perm, tse_api.hip), so a ring edge is one line instead of the
+// two that three of the four edges straddled with one fixed perimeter-first order.
+__host__ __device__ __forceinline__ int ppos(unsigned long long perm, int p) { return (int)((perm >> (4 * p)) & 15ull); }
 // qmin/qmax(k,q,e) of prim_advection_mod (:459) in the device layout [e][k / CL][q][k % CL]
 __device__ __forceinline__ size_t mm_idx(int e, int q, int k, int qsize) { return (((size_t)e * NCHUNK + k / CL) * qsize + q) * CL + (k % CL); }
 // Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
@@ -250,9 +261,7 @@ __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qs
 // plist/npwork: the patches this launch walks (nullptr: patches 0..npwork).  A multi-rank step launches every slab kernel
 // twice: first over the patches (plain kernels: elements, order/nwork) that touch another rank, so that their halo can travel
 // while the second launch computes the interior (tse_api.hip).
-constexpr int NER = 32;            // elements around a patch whose bounds the stage-3 kernel reads (a full 4x4 patch has 20)
-constexpr int BND_ENT = PS + NER;  // element entries of its bounds image in LDS: the patch's slots, then the element ring
-static_assert(BND_ENT * 4 <= FLAT_THREADS, "one 16-byte load per lane fills the bounds image");
+constexpr int NER = 32;            // elements around a patch whose bounds the stage-3 kernel reads (full 4x4, 6x4, 8x4 patches: 20, 24, 28)
 struct GatherArgs {
   Scr S;
   const int* slot_of;              // element -> slot of the scratch layout
@@ -270,10 +279,11 @@ struct GatherArgs {
   double* divdp_out;               // stage 1 (k_advance<0,0>): divdp = divergence_sphere(vn0) is formed here and stored (no k_divdp pass)
   const int* pering;               // [npatch][NER] elements around the patch (>= nelemd: received entry nelemd + i, stored behind the local elements)
   const unsigned char* pnb;        // [npatch][PS][8] neighbour d of a slot -> entry of the bounds image (slot, PS + ring entry, 255 = none)
+  const unsigned long long* pperm; // [slot] point order inside the slot (ppos)
 };
-struct BoundsLds { double v[2][BND_ENT][2][CL]; };   // [buffer][element entry][min|max][level of the chunk]: 6 KB
-constexpr int LDS_ZERO = PS * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
-struct PatchLds { double v[2][LDS_ENT][CL]; };   // 2 x 12.3 KB
+// bounds image of the stage-3 kernel: [buffer][element entry: the patch's slots, then the element ring][min|max][level of the chunk]
+template <int PSZ> struct BoundsLds { static constexpr int ENT = PSZ + NER; double v[2][ENT][2][CL]; };   // 6-8 KB
+template <int PSZ> struct PatchLds { double v[2][Patch<PSZ>::LDS_ENT][CL]; };   // 2 x 11.3 | 15.9 | 20.5 KB
 
 __device__ __forceinline__ double swz_xor4(double x) {   // value of lane ^ 4 (the other level of the pair)
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -283,8 +293,9 @@ __device__ __forceinline__ double swz_xor4(double x) {   // value of lane ^ 4 (t
 
 // block -> (patch, chunk), lane -> (slot of the patch, level of the chunk, row).  The 8 XCDs each take a contiguous range of
 // patches and walk it chunk by chunk, so that the patches whose own values are a block's ring are in flight on the same XCD.
-struct PatchId { int patch, slot, e, k, j; bool live, any; };
+struct PatchId { int patch, tslot /* patch * PSZ + position: index into the patch tables */, slot /* storage slot of the element */, e, k, j; bool live, any; };
 inline int patch_blocks(int npwork) { return 8 * ((npwork + 7) / 8) * NCHUNK; }
+template <int PSZ>
 __device__ __forceinline__ PatchId patch_slab(const GatherArgs& A) {
   const int npx = (A.npwork + 7) >> 3, x = blockIdx.x & 7, i = blockIdx.x >> 3;
   const int kc = i / npx, pi = x * npx + (i - kc * npx);
@@ -294,10 +305,11 @@ __device__ __forceinline__ PatchId patch_slab(const GatherArgs& A) {
   const int sl = threadIdx.x >> 4;
   P.k = kc * CL + ((threadIdx.x >> 2) & (CL - 1));
   P.j = threadIdx.x & 3;
-  P.slot = P.patch * PS + sl;
-  const int e = A.pslots[P.slot];
+  P.tslot = P.patch * PSZ + sl;
+  const int e = A.pslots[P.tslot];
   P.live = e >= 0;
-  P.e = P.live ? e : A.pslots[P.patch * PS];   // a hole recomputes the patch's first element and stores nothing
+  P.e = P.live ? e : A.pslots[P.patch * PSZ];   // a hole recomputes the patch's first element and stores nothing
+  P.slot = A.slot_of[P.e];
   return P;
 }
 
@@ -309,9 +321,11 @@ struct RowGather {
   unsigned lr[5];      // LDS byte offsets (buffer 0) of the lane's five neighbour values
   double rs[4];
 };
-__device__ __forceinline__ void gather_setup(RowGather& R, PatchLds& L, const GatherArgs& A, const PatchId& P) {
+template <int PSZ>
+__device__ __forceinline__ void gather_setup(RowGather& R, PatchLds<PSZ>& L, const GatherArgs& A, const PatchId& P) {
+  constexpr int NRMAX = Patch<PSZ>::NRMAX, LDS_ZERO = Patch<PSZ>::LDS_ZERO;
   if (threadIdx.x < 2 * CL) L.v[threadIdx.x / CL][LDS_ZERO][threadIdx.x % CL] = 0.0;   // target of absent contributions (read after the first barrier)
-  const int j = P.j, kk = P.k & (CL - 1), kc = P.k / CL, sl = P.slot - P.patch * PS;
+  const int j = P.j, kk = P.k & (CL - 1), kc = P.k / CL, sl = P.tslot - P.patch * PSZ;
   const bool edge = (j == 0) | (j == 3), odd = kk & 1;
   const int jt = j == 1 ? 0 : (j == 2 ? 3 : j);   // the edge row a middle row helps
   // (row, point, contribution index) of the row's five fetches
@@ -320,17 +334,19 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds& L, const Ga
   const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
   const unsigned chunk0 = (unsigned)kc * A.S.cse;                       // first entry of the chunk
   const int p0 = j * 4 + (odd ? 2 : 0);
-  R.own = ((chunk0 + (unsigned)P.slot * 16 + ppos(p0)) * CL + (kk & ~1)) * 8u;
-  R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(p0 + 1)) * CL + (kk & ~1)) * 8u;
+  const unsigned long long perm = A.pperm[P.slot];
+  R.own = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0)) * CL + (kk & ~1)) * 8u;
+  R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0 + 1)) * CL + (kk & ~1)) * 8u;
   R.lw = (unsigned)((sl * 16 + p0) * CL + (kk & ~1)) * 8u;
   unsigned short le[5];
 #pragma unroll
-  for (int m = 0; m < 5; m++) le[m] = A.plds[((size_t)P.slot * 16 + rw[m] * 4 + pt[m]) * 3 + cn[m]];
-  // ring: lanes 2r, 2r+1 load the two level pairs of ring entry r; lanes beyond the patch's ring re-read the zero slot
-  const int r = threadIdx.x >> 1, half = threadIdx.x & 1;
-  const unsigned ent = A.pring[(size_t)P.patch * NRMAX + r];           // unused entries of the table hold the zero slot
+  for (int m = 0; m < 5; m++) le[m] = A.plds[((size_t)P.tslot * 16 + rw[m] * 4 + pt[m]) * 3 + cn[m]];
+  // ring: lanes 2r, 2r+1 load the two level pairs of ring entry r (unused entries of the table hold the zero slot); the lanes
+  // beyond the table repeat its last entry (same address, same LDS word, same value)
+  const int r = min((int)(threadIdx.x >> 1), NRMAX - 1), half = threadIdx.x & 1;
+  const unsigned ent = A.pring[(size_t)P.patch * NRMAX + r];
   R.ring = ((chunk0 + ent) * CL + half * 2) * 8u;
-  R.lwr = (unsigned)((PS * 16 + r) * CL + half * 2) * 8u;              // r < NRMAX = 128 = 256 lanes / 2
+  R.lwr = (unsigned)((PSZ * 16 + r) * CL + half * 2) * 8u;
 #pragma unroll
   for (int m = 0; m < 5; m++) R.lr[m] = ((unsigned)le[m] * CL + kk) * 8u;
   load4(A.rspheremp + (size_t)P.e * 16 + j * 4, R.rs);
@@ -347,7 +363,8 @@ __device__ __forceinline__ void gather_issue(RowGather& R, const GatherArgs& A, 
 }
 // publish the lane's loads of tracer q in LDS buffer `b` and keep its own 4 values (level pair exchange: keep my level's half
 // of what I loaded, send the other half to lane ^ 4).  Holes publish their copy into their own (unreferenced) entries.
-__device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds& L, int b, int k, const GatherRaw& raw, double v[4]) {
+template <int PSZ>
+__device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds<PSZ>& L, int b, int k, const GatherRaw& raw, double v[4]) {
   const bool odd = k & 1;
   char* base = reinterpret_cast<char*>(&L.v[b][0][0]);
   *reinterpret_cast<double2*>(base + R.lw) = raw.w[0];
@@ -361,7 +378,8 @@ __device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds& L, 
 // all LDS writes of the workgroup have landed; the loads of the next tracer stay in flight (no vmcnt wait)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
 // the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
-__device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L, int b, int j, const double v[4], double out[4]) {
+template <int PSZ>
+__device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds<PSZ>& L, int b, int j, const double v[4], double out[4]) {
   const bool edge = (j == 0) | (j == 3);
   const char* base = reinterpret_cast<const char*>(&L.v[b][0][0]);
   const double f0 = *reinterpret_cast<const double*>(base + R.lr[0]), f1 = *reinterpret_cast<const double*>(base + R.lr[1]),
@@ -380,7 +398,8 @@ __device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds& L
 }
 // DSS of the extra plane on read, before the tracer loop of a DSS-on-read kernel (LDS buffer 1: the loop starts on buffer 0, and
 // its barrier of tracer 0 separates these reads from the publish of tracer 1 into buffer 1).  All lanes of the block call it.
-__device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds& L, const GatherArgs& A, const double* __restrict__ src, int plane,
+template <int PSZ>
+__device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds<PSZ>& L, const GatherArgs& A, const double* __restrict__ src, int plane,
                                                  int j, int k, double x[4]) {
   GatherRaw raw;
   double own[4];
@@ -394,10 +413,11 @@ __device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds& L, cons
 // stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
 struct RowStore { unsigned o0, o1; };   // plane-relative offsets (doubles) of the lane's two stores
-__device__ __forceinline__ RowStore row_store_setup(Scr S, int slot, int j, int k) {
+__device__ __forceinline__ RowStore row_store_setup(Scr S, const unsigned long long* __restrict__ pperm, int slot, int j, int k) {
   const int p0 = j * 4 + ((k & 1) ? 2 : 0);
   const unsigned base = (unsigned)(k / CL) * S.cse + (unsigned)slot * 16;
-  return RowStore{(base + ppos(p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(p0 + 1)) * CL + ((k & (CL - 1)) & ~1)};
+  const unsigned long long perm = pperm[slot];
+  return RowStore{(base + ppos(perm, p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(perm, p0 + 1)) * CL + ((k & (CL - 1)) & ~1)};
 }
 __device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[q][0] */, const RowStore& R, int k, bool live, const double v[4]) {
   const bool odd = k & 1;
@@ -450,31 +470,34 @@ __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned
 // needs the DSS'd stage-2 tracers in memory (k_lap1 does not store them).
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
-template <int RHS, int GIN = 0, bool DB = (GIN != 0)>
-__global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
+template <int RHS, int GIN = 0, bool DB = (GIN != 0), int PSZ = 16 /* block shape (GIN != 0): Patch<PSZ> */>
+__global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
                                                           const double* __restrict__ divdp_proj, double* __restrict__ qmin,
                                                           double* __restrict__ qmax, const double* __restrict__ dp0, GatherArgs GA) {
   static_assert(GIN == 0 || GIN == 1 || (GIN == 3 && RHS == 2), "plain inputs, gathered tracers, or gathered tracers and Laplacian");
-  __shared__ PatchLds lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
-  __shared__ BoundsLds bnd_;                    // (GIN == 3 only)
+  static_assert(GIN != 0 || PSZ == 16, "the plain kernels have no block shape");
+  __shared__ PatchLds<PSZ> lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
+  __shared__ BoundsLds<PSZ> bnd_;                    // (GIN == 3 only)
+  constexpr int BND_ENT = BoundsLds<PSZ>::ENT, LDS_ZERO = Patch<PSZ>::LDS_ZERO;
+  static_assert(BND_ENT * 4 <= Patch<PSZ>::THREADS, "one 16-byte load per lane fills the bounds image");
   constexpr bool NBR = GIN == 3;                // the limiter bounds are the min/max over the element and its neighbours of qmin/qmax, formed here
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
   PatchId pid{};
   if (GIN) {
-    pid = patch_slab(GA);
+    pid = patch_slab<PSZ>(GA);
     if (!pid.any) return;   // whole block (uniform): before any barrier
     e = pid.e; kc = pid.k; k = pid.live ? pid.k : NLEV; slot = pid.slot;
   } else {
     const SlabId sid = flat_slab(GA.nwork, GA.order);
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
-  const RowStore RS = row_store_setup(GA.S, slot, j, kc);
+  const RowStore RS = row_store_setup(GA.S, GA.pperm, slot, j, kc);
   RowGather RG;
-  if (GIN) gather_setup(RG, lds_[0], GA, pid);
+  if (GIN) gather_setup<PSZ>(RG, lds_[0], GA, pid);
   double vdss[4] = {0, 0, 0, 0};   // the previous stage's extra variable, DSS'd on read (stage 2: divdp_proj, which this stage's dp needs)
   if (GIN && GA.var_out) {
     gather_var_plane(RG, lds_[0], GA, Qn0, qsize, j, kc, vdss);
@@ -534,18 +557,18 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
   const double* bbase = qmin;
   if (NBR) {
     const int t = threadIdx.x, u = min(t >> 2, BND_ENT - 1), w = (t >> 1) & 1, h = t & 1;   // lanes beyond the image repeat its last entry
-    int el = u < PS ? GA.pslots[pid.patch * PS + u] : GA.pering[pid.patch * NER + (u - PS)];
+    int el = u < PSZ ? GA.pslots[pid.patch * PSZ + u] : GA.pering[pid.patch * NER + (u - PSZ)];
     if (el < 0) el = pid.e;   // hole
     bsrc = (unsigned)((((size_t)el * NCHUNK + kc / CL) * qsize) * CL + h * 2);   // + q*CL: entry index in qmin / qmax (< 2^32: the arrays are < 32 GB)
     bbase = w ? qmax : qmin;
     bdst = (unsigned)(((u * 2 + w) * CL + h * 2) * 8);
     // the 9 entries of a slab (its element, then the 8 neighbours) are shared out over the quad: row j takes entries j, j+4 (and 8)
-    const int sl = pid.live ? pid.slot - pid.patch * PS : 0, kk = kc & (CL - 1);
+    const int sl = pid.live ? pid.tslot - pid.patch * PSZ : 0, kk = kc & (CL - 1);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       const int d = j + 4 * i;   // 0: the element itself; d >= 1: neighbour d-1
       int n = sl;
-      if (d >= 1 && d < 9) { const int v = GA.pnb[((size_t)pid.patch * PS + sl) * 8 + (d - 1)]; if (v != 255) n = v; }
+      if (d >= 1 && d < 9) { const int v = GA.pnb[((size_t)pid.patch * PSZ + sl) * 8 + (d - 1)]; if (v != 255) n = v; }
       bnb[i] = (unsigned)((n * 2 * CL + kk) * 8);
     }
   }
@@ -691,24 +714,24 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, G
 // Q = Qdp/dp, element min/max, first weak Laplacian (pre-DSS) -> Bout
 // GIN == 1 (whole-step path; block = patch x chunk): Qn0 is the stage-2 pre-DSS scratch; the DSS'd Qdp is assembled on read
 // and not stored (k_advance<2,3> of stage 3 assembles it again itself).
-template <int GIN = 0>
-__global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
+template <int GIN = 0, int PSZ = 16>
+__global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double rdt,
                                                        const double* __restrict__ Qn0, double* __restrict__ Bout,
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax, GatherArgs GA) {
-  __shared__ PatchLds lds_;
+  __shared__ PatchLds<PSZ> lds_;
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
   PatchId pid{};
   if (GIN) {
-    pid = patch_slab(GA);
+    pid = patch_slab<PSZ>(GA);
     if (!pid.any) return;   // whole block (uniform): before any barrier
     e = pid.e; kc = pid.k; k = pid.live ? pid.k : NLEV; slot = pid.slot;
   } else {
     const SlabId sid = flat_slab(GA.nwork, GA.order);
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
-  const RowStore RS = row_store_setup(GA.S, slot, j, kc);
+  const RowStore RS = row_store_setup(GA.S, GA.pperm, slot, j, kc);
   LapGeo L;
   {
     RowGeo g;
@@ -723,7 +746,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_lap1(int nelemd, Dvv_t D, GeoP
   RowGather RG;
   GatherRaw graw;
   if (GIN) {
-    gather_setup(RG, lds_, GA, pid);
+    gather_setup<PSZ>(RG, lds_, GA, pid);
     if (GA.var_out) {   // the previous stage's extra variable (stage 3: eta_dot_dpdn), DSS'd on read
       double vdss[4];
       gather_var_plane(RG, lds_, GA, Qn0, qsize, j, kc, vdss);
@@ -814,17 +837,17 @@ __device__ __forceinline__ DssLane dss_lane(int nelemd) {
 // neighbour contributions are LDS reads; remote contributions sit in the halo columns of the scratch planes (k_unpack_halo).
 // mn_out/mx_out (MODE 1 only, may be null): element min/max of Q = Qdp/dp of the field just written, i.e. what the
 // next tracer step's first stage would compute with k_qminmax (prim_advection_mod.F90:764-775) -- saves that pass.
-template <int MODE>
-__global__ __launch_bounds__(FLAT_THREADS) void k_dss_patch(int qsize, const double* __restrict__ src, double* __restrict__ dst,
+template <int MODE, int PSZ = 16>
+__global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, const double* __restrict__ src, double* __restrict__ dst,
                                                             const double* __restrict__ Qn0, const double* __restrict__ dpnext,
                                                             double* __restrict__ mn_out, double* __restrict__ mx_out, GatherArgs GA) {
-  __shared__ PatchLds lds_;
-  const PatchId pid = patch_slab(GA);
+  __shared__ PatchLds<PSZ> lds_;
+  const PatchId pid = patch_slab<PSZ>(GA);
   if (!pid.any) return;   // whole block (uniform): before any barrier
   const int e = pid.e, kc = pid.k, k = pid.live ? pid.k : NLEV, j = pid.j;
   RowGather RG;
   GatherRaw graw;
-  gather_setup(RG, lds_, GA, pid);
+  gather_setup<PSZ>(RG, lds_, GA, pid);
   double dn[4] = {1, 1, 1, 1}, q0x[4] = {0, 0, 0, 0};
   if (MODE == 1 && mn_out) load4(dpnext + ((size_t)e * NLEV + kc) * 16 + j * 4, dn);
   auto fetch = [&](int q) {
@@ -1062,6 +1085,14 @@ __device__ __forceinline__ double ppm_integ(double c0, double c1, double c2, dou
 // data-dependent number of cells per level (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209).
 // Only taken by elements whose Lagrangian interfaces moved by more than one layer somewhere (see k_remap).
 // Plain straight-line code on purpose: lambdas/arrays passed by pointer ended up in scratch memory inside this loop.
+// ALG2 (vert_remap_q_alg = 2, control_mod.F90:61-66): no mirrored ghost cells -- the two cells at either end of a column are
+// piecewise constant (prim_advection_mod.F90:336-341); the parabolas of cells 3 .. nlev-2 see no ghost value either way
+// (dma(2..nlev-1), ai(2..nlev-2): :283-314), so they are those of the mirrored form.
+template <bool ALG2>
+__device__ __forceinline__ void ppm_alg2(int cell, double a0, double& c0, double& c1, double& c2) {
+  if (ALG2) { const bool pc = cell <= 2 || cell >= NLEV - 1; c0 = pc ? a0 : c0; c1 = pc ? 0. : c1; c2 = pc ? 0. : c2; }
+}
+template <bool ALG2>
 __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
                                                    double* __restrict__ mn_out, double* __restrict__ mx_out) {
   const int p = tid & 15;
@@ -1096,6 +1127,7 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
     double masso_kk = 0.0, massn1 = 0.0;
     double c0, c1, c2;
     remap_coefs(ai_m1, ai_0, a0, c0, c1, c2);
+    ppm_alg2<ALG2>(kk, a0, c0, c1, c2);
     for (int k = 1; k <= NLEV; k++) {
       const int kt = S.kid[k - 1][p];
       while (kk < kt) {
@@ -1106,6 +1138,7 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
         dma_m1 = dma_0; dma_0 = dma_p1; dma_p1 = remap_dma_at(S, kk + 1, p, a0, ap1, ap2);
         ai_m1 = ai_0; ai_0 = remap_ai_at(S, kk, p, a0, ap1, dma_p1, dma_0);
         remap_coefs(ai_m1, ai_0, a0, c0, c1, c2);
+        ppm_alg2<ALG2>(kk, a0, c0, c1, c2);
       }
       double z1, zz2, z3;
       ppm_zterms(S.z2[k - 1][p], z1, zz2, z3);
@@ -1140,7 +1173,7 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
 // in the order of the sweep), primes the 5-cell window from the cells around its first level with the formulas of the
 // sweep, runs the level before its first one with the stores turned into a dump (that yields the running new-grid mass), and
 // then its REMAP_PF levels: the same values in the same order as a whole sweep produces.
-template <int NT>
+template <int NT, bool ALG2>
 __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
                                                    double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink) {
   const int p = tid & 15, slots = (nthreads >> 4) * NT;
@@ -1227,6 +1260,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
       double c0, c1, c2;
       remap_coefs(al, ar, a0, c0, c1, c2);
+      ppm_alg2<ALG2>(o ? k + 1 : k, a0, c0, c1, c2);
       const double massn2 = fma(ppm_integ(c0, c1, c2, z1, zz2, z3), dsel, ms);
       const double qnew = massn2 - massn1[t];
       colw[t][(size_t)(k - 1) * 16] = qnew;
@@ -1336,7 +1370,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 
 #pragma clang fp contract(fast)   // (the default of the rest of the file)
 
-template <int NT>
+template <int NT, bool ALG2 = false>
 __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
                                                          const double* __restrict__ hybi, const double* __restrict__ dp,
                                                          const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
@@ -1455,8 +1489,8 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
   }
   __syncthreads();
   // ---- phase 2: data part
-  if (S.slow) remap_columns_generic(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
-  else remap_columns_fast<NT>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink);
+  if (S.slow) remap_columns_generic<ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
+  else remap_columns_fast<NT, ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink);
 }
 
 // ---------------------------------------------------------------------------------------------------

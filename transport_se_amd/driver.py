@@ -113,7 +113,7 @@ def check_schedules_match(sched, minmax_len, rank, dist_mod):
 
 class PrimRun:
     def __init__(self, ne, qsize, test_case=1, nu_q=None, tstep=None, rsplit=3, rank=0, world=1, device=0,
-                 dist_mod=None, torch_mod=None, exchange="rccl"):
+                 dist_mod=None, torch_mod=None, exchange="rccl", vert_remap_q_alg=0):
         """exchange (world > 1): "rccl" = in-library RCCL send/recv (production), "torch" = torch.distributed P2P ops in the
         exchange callback, "staged" = callback with host-staged slots over a CPU backend (ranks may share a GPU)."""
         self.ne, self.qsize, self.rsplit, self.test_case = ne, qsize, rsplit, test_case
@@ -144,20 +144,31 @@ class PrimRun:
         self.hip_device = device
         self.rank, self.world = rank, world
         self.hip = HipMod(self.elem, cm.dvv(), (self.hv.hyai, self.hv.hybi, self.hv.ps0), qsize, self.nu_q,
-                          rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=callback)
+                          rsplit=rsplit, device=device, schedule=dict(send=desc["send"], recv=desc["recv"]), exchange=callback,
+                          vert_remap_q_alg=vert_remap_q_alg)
         if world > 1:
             check_schedules_match(desc, (self.hip.minmax_send_len, self.hip.minmax_recv_len), rank, dist_mod)
             if exchange == "rccl":
-                box = [HipMod.comm_unique_id() if rank == 0 else None]
-                dist_mod.broadcast_object_list(box, src=0)
+                # ncclCommInitRank is a blocking collective: a rank that cannot take part must say so BEFORE anyone enters it,
+                # or its peers wait in the bootstrap for ever.  So: local pre-check on every rank, agreement over the control
+                # plane, and only then the collective (whose own failures are symmetric: every rank gets an error back).
                 err = None
                 try:
-                    self.hip.comm_init(box[0], rank, world)
+                    self.hip.comm_precheck(rank, world)
                 except RuntimeError as ex:
                     err = str(ex)
                 errs = [None] * world
                 dist_mod.all_gather_object(errs, err)
                 bad = [(r, e) for r, e in enumerate(errs) if e]
+                if not bad:
+                    box = [HipMod.comm_unique_id() if rank == 0 else None]
+                    dist_mod.broadcast_object_list(box, src=0)
+                    try:
+                        self.hip.comm_init(box[0], rank, world)
+                    except RuntimeError as ex:
+                        err = str(ex)
+                    dist_mod.all_gather_object(errs, err)
+                    bad = [(r, e) for r, e in enumerate(errs) if e]
                 if bad:
                     # every rank leaves RCCL together and says so: host-staged slots over the control-plane backend
                     self.hip.comm_abort()

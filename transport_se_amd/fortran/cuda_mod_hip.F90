@@ -21,7 +21,8 @@ module cuda_mod
   use hybvcoord_mod,  only : hvcoord_t
   use hybrid_mod,     only : hybrid_t
   use parallel_mod,   only : abortmp
-  use control_mod,    only : nu_q, limiter_option, rsplit
+  use control_mod,    only : nu_q, limiter_option, rsplit, qsplit, vert_remap_q_alg, hypervis_subcycle_q, hypervis_power, &
+                             hypervis_scaling
   use schedtype_mod,  only : schedule
   implicit none
   private
@@ -50,6 +51,7 @@ module cuda_mod
      integer(c_int) :: nsend;  type(c_ptr) :: send_peer, send_ptrP, send_lengthP
      integer(c_int) :: nrecv;  type(c_ptr) :: recv_peer, recv_ptrP, recv_lengthP
      type(c_funptr) :: exchange; type(c_ptr) :: exchange_user
+     integer(c_int) :: vert_remap_q_alg
   end type tse_init_args
 
   interface
@@ -67,6 +69,9 @@ module cuda_mod
      end function
      integer(c_int) function tse_comm_init(ctx, id, rank, nranks) bind(C, name='tse_comm_init')
        import; type(c_ptr), value :: ctx, id; integer(c_int), value :: rank, nranks
+     end function
+     integer(c_int) function tse_comm_precheck(ctx, rank, nranks) bind(C, name='tse_comm_precheck')
+       import; type(c_ptr), value :: ctx; integer(c_int), value :: rank, nranks
      end function
      integer(c_int) function tse_copy_qdp_h2d(ctx, q, stride, qsize_d, nt) bind(C, name='tse_copy_qdp_h2d')
        import; type(c_ptr), value :: ctx, q; integer(c_size_t), value :: stride; integer(c_int), value :: qsize_d, nt
@@ -171,6 +176,15 @@ contains
     character(len=16) :: xmode
     logical :: use_rccl
     character(kind=c_char), target, save :: comm_id(128)
+    ! What the device path does not implement is refused here, with the reference's own error route, instead of being silently
+    ! replaced by the default behaviour: the tracer time levels assume qsplit = 1 (TimeLevel_Qdp, time_mod.F90:85-109), the
+    ! hyperviscosity is the single constant-coefficient application of euler_step (prim_advection_mod.F90:796-826; no tracer
+    ! subcycling, no variable / tensor coefficient: derivative_mod.F90:2438-2445), the remap is remap_Q_ppm with ghost-cell
+    ! variant 0|1 or 2 (prim_advection_mod.F90:230-341).
+    if (qsplit /= 1) call abortmp('cuda_mod_init(hip): qsplit must be 1')
+    if (hypervis_subcycle_q /= 1) call abortmp('cuda_mod_init(hip): hypervis_subcycle_q must be 1')
+    if (hypervis_power /= 0 .or. hypervis_scaling /= 0) call abortmp('cuda_mod_init(hip): hypervis_power and hypervis_scaling must be 0')
+    if (vert_remap_q_alg < 0 .or. vert_remap_q_alg > 2) call abortmp('cuda_mod_init(hip): vert_remap_q_alg must be 0, 1 or 2')
     allocate(putm(8,nelemd), getm(8,nelemd), revm(8,nelemd))
     do ie = 1, nelemd
        putm(:,ie) = elem(ie)%desc%putmapP(1:8)
@@ -208,6 +222,7 @@ contains
     a%nsend = ns; a%send_peer = c_loc(speer); a%send_ptrP = c_loc(sptr); a%send_lengthP = c_loc(slen)
     a%nrecv = nr; a%recv_peer = c_loc(rpeer); a%recv_ptrP = c_loc(rptr); a%recv_lengthP = c_loc(rlen)
     a%exchange = c_null_funptr; a%exchange_user = c_null_ptr
+    a%vert_remap_q_alg = vert_remap_q_alg
     ! bndry_exchangeV: TSE_EXCHANGE=rccl (one rank per GPU) lets the library exchange the halo itself with RCCL send/recv on its
     ! own stream -- the communicator id travels over MPI once, below; otherwise the MPI body of tse_f_exchange is the callback
     call get_environment_variable('TSE_EXCHANGE', xmode)
@@ -224,10 +239,16 @@ contains
                   'tse_host_register')
     endif
     if (use_rccl) then
-       if (hybrid%par%rank == 0) call check(tse_comm_unique_id(c_loc(comm_id)), 'tse_comm_unique_id')
-       call MPI_Bcast(comm_id, 128, MPI_CHARACTER, 0, hybrid%par%comm, ierr)
-       rc_comm = tse_comm_init(ctx, c_loc(comm_id), int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int))
+       ! ncclCommInitRank is a blocking collective: every rank first checks what it can check alone, and only if ALL are ready
+       ! does anyone enter it (a rank failing alone inside would strand the others in the bootstrap)
+       rc_comm = tse_comm_precheck(ctx, int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int))
        call MPI_Allreduce(rc_comm, rc_any, 1, MPI_INTEGER, MPI_MAX, hybrid%par%comm, ierr)
+       if (rc_any == 0) then
+          if (hybrid%par%rank == 0) call check(tse_comm_unique_id(c_loc(comm_id)), 'tse_comm_unique_id')
+          call MPI_Bcast(comm_id, 128, MPI_CHARACTER, 0, hybrid%par%comm, ierr)
+          rc_comm = tse_comm_init(ctx, c_loc(comm_id), int(hybrid%par%rank,c_int), int(hybrid%par%nprocs,c_int))
+          call MPI_Allreduce(rc_comm, rc_any, 1, MPI_INTEGER, MPI_MAX, hybrid%par%comm, ierr)
+       endif
        if (rc_any /= 0) then     ! every rank leaves RCCL together: the halo goes through tse_f_exchange (MPI) instead
           call check(tse_comm_abort(ctx), 'tse_comm_abort')
           if (hybrid%par%rank == 0) write(*,'(a)') ' cuda_mod_hip: WARNING: RCCL communicator could not be initialised; halo exchange over MPI'

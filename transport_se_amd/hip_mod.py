@@ -32,7 +32,7 @@ def _vp(a):
 
 class HipMod:
     def __init__(self, elem, deriv_Dvv, hvcoord, qsize, nu_q, limiter_option=8, rsplit=3, device=-1,
-                 schedule=None, exchange=None):
+                 schedule=None, exchange=None, vert_remap_q_alg=0):
         """cuda_mod_init.  hvcoord = (hyai, hybi, ps0).  schedule = dict(send=[(peer, ptrP, lengthP)...],
         recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr, kind) -> 0."""
         L = _lib.lib()
@@ -43,6 +43,7 @@ class HipMod:
         a = _lib.InitArgs()
         a.nelemd, a.qsize, a.device, a.nu_q = self.nelemd, self.qsize, device, float(nu_q)
         a.limiter_option, a.rsplit = int(limiter_option), int(rsplit)
+        a.vert_remap_q_alg = int(vert_remap_q_alg)   # control_mod.F90:61-66 (0|1 mirrored ghost cells, 2 piecewise-constant ends)
 
         def keep(x, dtype):
             x = np.ascontiguousarray(x, dtype=dtype); self._keep.append(x); return x
@@ -95,6 +96,22 @@ class HipMod:
         if L.tse_comm_unique_id(buf):
             raise TseError(L.tse_last_error().decode())
         return buf.raw
+
+    def comm_precheck(self, rank, nranks):
+        """everything comm_init can find wrong without the other ranks (raises TseError); hosts agree on the outcome over
+        their control plane BEFORE anyone enters the blocking collective comm_init"""
+        self._chk(self.L.tse_comm_precheck(self.h, int(rank), int(nranks)))
+
+    @staticmethod
+    def comm_version():
+        """dict(runtime=, built=, path=): the RCCL this process resolved vs. the headers the library was built with"""
+        rt, bl = C.c_int(), C.c_int()
+        buf = C.create_string_buffer(512)
+        L = _lib.lib()
+        if L.tse_comm_version(C.byref(rt), C.byref(bl), buf, 512):
+            raise TseError(L.tse_last_error().decode())
+        fmt = lambda v: "%d.%d.%d" % (v // 10000, v // 100 % 100, v % 100)   # noqa: E731
+        return dict(runtime=fmt(rt.value), built=fmt(bl.value), path=buf.value.decode())
 
     def comm_init(self, comm_id, rank, nranks):
         """collective over all ranks; afterwards the library exchanges the halo itself (no callback)"""
@@ -226,8 +243,14 @@ class HipMod:
         self._chk(self.L.tse_dcmip_step_inputs(self.h, nstep, tstep))
 
     def prim_run_subcycle(self, tstep, nsub, nstep):
+        """nsub remap cycles from step count nstep; returns the new step count.  On "negative layer thickness" the TseError carries
+        .rc = 2 and .nstep = the step count at the end of the first failing cycle (prim_advection_mod.F90:1323 aborts there)."""
         ns = C.c_int(nstep)
-        self._chk(self.L.tse_prim_run_subcycle(self.h, tstep, nsub, C.byref(ns)))
+        rc = self.L.tse_prim_run_subcycle(self.h, tstep, nsub, C.byref(ns))
+        if rc:
+            err = TseError(self.L.tse_last_error().decode())
+            err.rc, err.nstep = rc, ns.value
+            raise err
         return ns.value
 
     def synchronize(self):

@@ -12,7 +12,9 @@ ctl_nl/vert_nl keys the tracer path reads are honoured; output (analysis_nl), re
 ignored.  At the end it prints the error-norm line the reference's NCL script prints and the tracer-mass lines; both are
 computed reproducibly (diagnostics.py), so the same run prints the same digits on 1, 2, 4 or 8 GPUs.
 Under an MPI-style launcher (mpiexec/srun: PMI_RANK, OMPI_COMM_WORLD_RANK or SLURM_PROCID in the environment) the ranks
-are taken from it; the control plane is torch.distributed/gloo on MASTER_ADDR:MASTER_PORT (default 127.0.0.1:29531).
+are taken from it; the control plane is torch.distributed/gloo on MASTER_ADDR:MASTER_PORT (default 127.0.0.1:29531 when every
+rank runs on this node; several nodes must set MASTER_ADDR; one GPU per LOCAL rank is required).  No run on more than one
+physical GPU has been recorded yet: the multi-rank evidence is staged ranks sharing a GPU and loopback rehearsals.
 """
 import argparse
 import os
@@ -27,7 +29,9 @@ import numpy as np
 from . import diagnostics as dg
 
 DEFAULTS = dict(ne=0, qsize=4, ndays=0, nmax=12, tstep=0.0, nu=0.0, nu_q=-1.0, rsplit=0, qsplit=1, limiter_option=0,
-                hypervis_order=0, test_case="", statefreq=1, vfile_mid="", vfile_int="", disable_diagnostics=False)
+                hypervis_order=0, test_case="", statefreq=1, vfile_mid="", vfile_int="", disable_diagnostics=False,
+                # control_mod defaults (control_mod.F90:48,61-66,134-140) of the keys the tracer path depends on
+                vert_remap_q_alg=0, hypervis_subcycle_q=1, hypervis_power=0.0, hypervis_scaling=0.0)
 
 
 def parse_namelists(text):
@@ -83,6 +87,13 @@ def settings(groups):
         raise SystemExit("prim_main: only limiter_option = 8 is supported (the only limiter the reference wires)")
     if s["rsplit"] <= 0 or s["qsplit"] != 1:
         raise SystemExit("prim_main: needs rsplit > 0 (vertically lagrangian) and qsplit = 1")
+    # what the device path does not implement is refused, never silently replaced (the Fortran seam aborts on the same keys)
+    if s["vert_remap_q_alg"] not in (0, 1, 2):
+        raise SystemExit("prim_main: vert_remap_q_alg = %r (0|1: PPM with mirrored ghost cells, 2: piecewise-constant boundary cells)" % (s["vert_remap_q_alg"],))
+    if s["hypervis_subcycle_q"] != 1:
+        raise SystemExit("prim_main: hypervis_subcycle_q = %r is not supported (1 only)" % (s["hypervis_subcycle_q"],))
+    if s["hypervis_power"] != 0 or s["hypervis_scaling"] != 0:
+        raise SystemExit("prim_main: hypervis_power / hypervis_scaling must be 0 (constant-coefficient hyperviscosity only)")
     tc = str(s["test_case"]).lower()
     if not tc.startswith("dcmip1-"):
         raise SystemExit("prim_main: test_case must be dcmip1-1 or dcmip1-2")
@@ -106,6 +117,18 @@ def _rank_world():
     return 0, 1, 0
 
 
+def _local_world(world):
+    """ranks on this node (LOCAL_WORLD_SIZE and its MPI / SLURM spellings); all of them when the launcher does not say"""
+    env = os.environ
+    for k in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"):
+        if k in env:
+            try:
+                return max(1, min(world, int(str(env[k]).split("(")[0])))
+            except ValueError:
+                pass
+    return world
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="prim_main")
     ap.add_argument("--gpus", type=int, default=0, help="start this many ranks (one per GPU) and feed them the namelist from stdin")
@@ -123,16 +146,32 @@ def main(argv=None):
         os.unlink(f.name)
         return rc
     rank, world, local = _rank_world()
+    local_world = _local_world(world)
     dist = torch = None
     exchange = os.environ.get("TSE_EXCHANGE", "rccl")
+    # a rank stuck in communicator set-up or in a halo exchange whose peer died must not block the job for ever (the reference's
+    # abortmp = MPI_Abort ends every rank): exit non-zero after TSE_WATCHDOG_S seconds without a result (0 disables)
+    limit = float(os.environ.get("TSE_WATCHDOG_S", "7200"))
+    watchdog = None
+    if world > 1 and limit > 0:
+        import threading
+
+        def give_up():
+            print("prim_main: rank %d has no result after %g s (TSE_WATCHDOG_S): giving up" % (rank, limit), file=sys.stderr, flush=True)
+            os._exit(4)
+        watchdog = threading.Timer(limit, give_up); watchdog.daemon = True; watchdog.start()
     if world > 1:
         import torch
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        if local_world == world:   # every rank on this node: the loopback defaults are safe (the container hostname may not resolve)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        elif "MASTER_ADDR" not in os.environ:
+            raise SystemExit("prim_main: %d ranks on several nodes (%d on this one): set MASTER_ADDR / MASTER_PORT for the control plane" % (world, local_world))
         ndev = torch.cuda.device_count()
-        if exchange != "staged" and ndev < world:
-            raise SystemExit("prim_main: %d ranks but %d GPU(s) visible (TSE_EXCHANGE=staged rehearses several ranks on one GPU)" % (world, ndev))
+        if exchange != "staged" and ndev < local_world:   # one GPU per LOCAL rank (ranks on other nodes have their own)
+            raise SystemExit("prim_main: %d ranks on this node but %d GPU(s) visible (TSE_EXCHANGE=staged rehearses several ranks on one GPU)"
+                             % (local_world, ndev))
         local = local % max(ndev, 1)
         if exchange == "torch":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -149,7 +188,7 @@ def main(argv=None):
     from . import cube_mesh as cm
     from .driver import PrimRun
     run = PrimRun(s["ne"], s["qsize"], test_case=s["test"], nu_q=s["nu_q"], tstep=s["tstep"], rsplit=s["rsplit"], rank=rank, world=world,
-                  device=local, dist_mod=dist, torch_mod=torch, exchange=exchange)
+                  device=local, dist_mod=dist, torch_mod=torch, exchange=exchange, vert_remap_q_alg=s["vert_remap_q_alg"])
     hip, gid, nelem = run.hip, run.mine, run.nelem
     say = print if rank == 0 else (lambda *x, **k: None)
 
@@ -216,6 +255,8 @@ def main(argv=None):
             print("Q%d mass: %22.14E -> %22.14E (relative change %10.3e)" % (t + 1, m0[t], m1[t], (m1[t] - m0[t]) / max(abs(m0[t]), 1e-300)))
         print("prim_run wall %.3f s: %.4e tracer-DOF-steps/s on %d rank(s)" % (float(stack[:, 0].max()), nelem * 16 * 72 * s["qsize"] * nsteps / float(stack[:, 0].max()), world))
     run.close()
+    if watchdog:
+        watchdog.cancel()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
