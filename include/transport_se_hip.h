@@ -112,6 +112,9 @@ int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
 int tse_comm_abort(tse_ctx *ctx);
 /* number of local elements that touch another rank (computed first in every stage) and that do not */
 int tse_boundary_layout(tse_ctx *ctx, int *n_boundary, int *n_interior);
+/* the same in patches (the blocks of the DSS-on-read kernels; the rank-boundary elements are grouped into thin patches of their own,
+ * so that the first launch of a stage stays a small fraction of the whole) */
+int tse_patch_layout(tse_ctx *ctx, int *np_boundary, int *np_interior);
 
 /* Optional: declare the host's element array (elem(1) .. elem(nelemd), contiguous, alive until tse_finalize).  It is page-locked
  * once and every later field copy whose host side lies inside it is a single 2-D DMA with pitch = sizeof(element_t) straight

@@ -28,7 +28,7 @@ def _hip(o, elem, alg):
 @pytest.mark.parametrize("generic", ["0", "1"])
 def test_remap_q_ppm_alg2_single_call_vs_reference(gold, monkeypatch, generic):
     g = gold("ref_ne2_alg2.npz")
-    o = po.Oracle(2, 5, nu_q=1e19)
+    o = po.Oracle(2, int(g["remap_Qin"].shape[1]), nu_q=1e19)
     elem = elem_from_oracle(o)
     monkeypatch.setenv("TSE_REMAP_GENERIC", generic)      # the lockstep and the generic column loop
     hip = _hip(o, elem, 2)

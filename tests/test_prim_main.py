@@ -143,3 +143,23 @@ def test_preqx_prints_the_same_digits_on_1_2_and_4_ranks(tmp_path):
         assert many == one, "\n".join(["%d ranks:" % n] + many + ["1 rank:"] + one)
     stats = open(os.path.join(str(tmp_path), "HommeTime_stats")).read()
     assert " 4 " in stats.splitlines()[1]                         # processes column of the last (4-rank) run
+
+
+@pytest.mark.gpu
+def test_one_rank_meeting_a_negative_layer_thickness_ends_every_rank(tmp_path):
+    """the reference aborts the whole job in the remap that meets a negative layer thickness (abortmp = MPI_Abort,
+    prim_advection_mod.F90:1323).  Here rank 1 of 2 alone gets return code 2 from its remap (TSE_TEST_FAIL_REMAP_RANK); the healthy
+    rank would otherwise wait in the next halo exchange for ever.  The job must end non-zero, with the message, well inside the
+    watchdog -- no hang, no silent success."""
+    import time
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(TSE_EXCHANGE="staged", TSE_TEST_FAIL_REMAP_RANK="1", TSE_WATCHDOG_S="150")
+    nl = NL.replace("nmax = 6             ! six tracer steps", "nmax = 12")
+    t0 = time.time()
+    res = subprocess.run([PREQX, "--gpus", "2"], input=nl.encode(), cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)
+    took = time.time() - t0
+    out = res.stdout.decode()
+    assert res.returncode != 0, out[-2000:]
+    assert "ABORTING WITH ERROR: negative layer thickness" in out and "tracer step 3" in out, out[-2000:]
+    assert "DCMIP 1-1:" not in out          # no result line from a job that failed
+    assert took < 200, took                 # the launcher ended the healthy rank (its own watchdog would have at 150 s)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--ne", type=int, default=120); ap.add_argument("--qsize", type=int, default=35)
     ap.add_argument("--world", type=int, default=8); ap.add_argument("--rank", type=int, default=-1)
     ap.add_argument("--cycles", type=int, default=2)
+    ap.add_argument("--verify", action="store_true", help="also compare one DSS-on-read step with the one-DSS-pass-per-stage route on the device")
     a = ap.parse_args()
     from transport_se_amd import cube_mesh as cm
     from transport_se_amd.driver import NU_Q, TSTEP, partition
@@ -57,10 +58,38 @@ def main():
         kt = {k: round(h.kernel_time(k)[0] / 3, 3) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap", "level", "dcmip")}
         h.timing(False)
         nb, ni = h.boundary_layout()
+        pb, pi = h.patch_layout()
         ncol = sum(s[2] for s in d["send"])
-        print(json.dumps({"rank": rank, "world": a.world, "elements": int(mine.size), "boundary_elements": nb, "neighbour_ranks": len(set(s[0] for s in d["send"])),
-                          "send_columns": int(ncol), "main_message_MB": round(ncol * (a.qsize + 1) * 72 * 8 / 1e6, 1),
-                          "ms_per_step": round(ms, 3), "kernel_ms_per_step_timing_mode": kt}), flush=True)
+        out = {"rank": rank, "world": a.world, "ne": a.ne, "qsize": a.qsize, "elements": int(mine.size), "boundary_elements": nb,
+               "boundary_patches": pb, "interior_patches": pi, "first_launch_fraction_of_patches": round(pb / max(pb + pi, 1), 4),
+               "neighbour_ranks": len(set(s[0] for s in d["send"])), "send_columns": int(ncol),
+               "main_message_MB": round(ncol * (a.qsize + 1) * 72 * 8 / 1e6, 1), "ms_per_step": round(ms, 3), "kernel_ms_per_step_timing_mode": kt}
+        import torch   # (already in the process: _lib loads it first) -- device memory in use with every field of the rank allocated
+        free, total = torch.cuda.mem_get_info(0)
+        out["device_memory_used_GB"] = round((total - free) / 1e9, 2)
+        if a.verify:
+            # one tracer step from the initial state, DSS on read against one DSS pass per stage (same loopback halo in both):
+            # the two routes must agree to the step tolerance at this shape, too
+            def dev(name, shape):
+                ptr, _ = h.device_ptr(name)
+                iface = {"shape": shape, "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+                return torch.as_tensor(type("DevArr", (), {"__cuda_array_interface__": iface})(), device="cuda:0")
+            Q = dev("qdp", (2, int(mine.size), a.qsize, 72, 16))
+            res, launches = [], []
+            for env in ("1", "0"):
+                os.environ["TSE_DSS_ON_READ"] = env
+                h.dcmip_set_initial(); h.dcmip_step_inputs(0, tstep)
+                h.timing(True)
+                h.advec_tracers_remap_rk2(tstep, 1, 2); h.synchronize()
+                launches.append(h.kernel_time("dss")[1])      # 1 tracer DSS pass with DSS on read, 4 with one pass per stage
+                h.timing(False)
+                res.append(Q[1].clone())
+            os.environ.pop("TSE_DSS_ON_READ")
+            out["dss_passes_of_the_two_routes"] = launches
+            out["dss_on_read_vs_per_stage_rel"] = float((res[0] - res[1]).abs().max() / res[0].abs().max())
+            out["finite"] = bool(torch.isfinite(res[0]).all())
+            del res
+        print(json.dumps(out), flush=True)
         h.close()
 
 

@@ -362,6 +362,11 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     // from its south-west corner.  The 4 x 4 tiling (set 0) is also the STORAGE order of the scratch fields (slot = patch * 16 +
     // position); the wider shapes (6 x 4, 8 x 4: sets 1, 2) are built only for the kernels that were given them (patch_shape).
     auto ring_key = [](const int2& t) { return t.x >= 0 ? (long)t.x * 16 + t.y : -(long)(-(t.x + 2)) - 1; };
+    std::vector<char> isb(n, 0);   // elements that touch another rank
+    for (const int2& q : send_src) isb[q.x] = 1;
+    for (const int2& q : mm_src) isb[q.x] = 1;
+    // TSE_BOUNDARY_STRIPS=0: no thin patches along the rank boundary (A/B; the tiling then is the single-rank one everywhere)
+    const bool strips = !(getenv("TSE_BOUNDARY_STRIPS") && atoi(getenv("TSE_BOUNDARY_STRIPS")) == 0);
     auto build = [&](int psz, std::vector<std::vector<int>>& patches, std::vector<int>& pid) {
       const int pw = psz / 4, nrmax = patch_nrmax(psz);
       pid.assign(n, -1);
@@ -388,6 +393,34 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
         std::sort(refs.begin(), refs.end());
         return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
       };
+      // Rank-boundary elements first, as THIN patches: a stage's first launch covers the patches that own a column of a send slot
+      // (split_stage), and with the regular tiling a 4 x 4 patch is such a patch as soon as one of its elements is -- a quarter of
+      // all patches on 8 ranks, for 6 % of the elements.  So the boundary elements are strung together along the boundary
+      // (element by element over the 8-neighbourhood, no interior element joins), as many per patch as the halo ring and the
+      // element ring allow: about ten (a 1 x 10 strip has a ring of 92), and the first launch shrinks to a tenth of the patches.
+      if (strips) {
+        const int maxlen = psz;
+        for (int seed = 0; seed < n; seed++) {
+          if (!isb[seed] || pid[seed] >= 0) continue;
+          const int me = (int)patches.size();
+          std::vector<int> cand{seed};
+          pid[seed] = me;
+          bool grew = true;
+          while (grew && (int)cand.size() < maxlen) {
+            grew = false;
+            // the next link of the chain: an unassigned boundary element next to the most recently added one, else next to any
+            for (int back = (int)cand.size() - 1; back >= 0 && !grew; back--)
+              for (int d = 0; d < 8 && !grew; d++) {
+                const int nb = nbr[cand[back] * 8 + d];
+                if (nb < 0 || !isb[nb] || pid[nb] >= 0) continue;
+                pid[nb] = me; cand.push_back(nb);
+                if (ring_size(cand, me) <= nrmax && ering_size(cand, me) <= NER) grew = true;
+                else { pid[nb] = -1; cand.pop_back(); }
+              }
+          }
+          patches.push_back(cand);
+        }
+      }
       for (int seed = 0; seed < n; seed++) {
         if (pid[seed] >= 0) continue;
         const int me = (int)patches.size();
@@ -450,9 +483,6 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
       }
     }
     const bool ab_noring = getenv("TSE_AB_NORING") && atoi(getenv("TSE_AB_NORING"));   // A/B: no halo-ring loads at all (WRONG results; bounds what the ring costs)
-    std::vector<char> isb(n, 0);   // elements that touch another rank
-    for (const int2& q : send_src) isb[q.x] = 1;
-    for (const int2& q : mm_src) isb[q.x] = 1;
     // ---- the tables of every tiling in use
     for (int si = 0; si < 3; si++) {
       if (!want[si]) continue;
@@ -634,6 +664,12 @@ int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   return 0;
 }
 int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
+// patches of the storage tiling that touch another rank (launched first in every stage) and that do not
+int tse_patch_layout(tse_ctx* c, int* np_boundary, int* np_interior) {
+  if (np_boundary) *np_boundary = c->pset[0].np_bnd;
+  if (np_interior) *np_interior = c->pset[0].np_int;
+  return 0;
+}
 int tse_invalidate_cache(tse_ctx* c) { set_bounds_cache(c, 0); c->dcmip_static = false; return 0; }
 
 // ---- RCCL communicator ----------------------------------------------------------------------------
@@ -1238,10 +1274,12 @@ static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefe
   if (n0_qdp == np1_qdp || n0_qdp < 1 || n0_qdp > 2 || np1_qdp < 1 || np1_qdp > 2)
     return fail("advec_tracers_remap_rk2: time levels n0_qdp=%d np1_qdp=%d", n0_qdp, np1_qdp);
   bool gor = dss_on_read();
-  if (gor && c->tps * 8 >= ((size_t)1 << 32)) {   // gather offsets are 32-bit bytes within a plane
+  // gather offsets are 32-bit bytes within a plane; TSE_TEST_PLANE_LIMIT lowers the 4 GiB limit so that tests reach the fallback
+  const size_t plane_limit = getenv("TSE_TEST_PLANE_LIMIT") ? (size_t)strtoull(getenv("TSE_TEST_PLANE_LIMIT"), nullptr, 10) : ((size_t)1 << 32);
+  if (gor && c->tps * 8 >= plane_limit) {
     static bool said = false;
     if (!said) {
-      fprintf(stderr, "transport_se_hip: a scratch plane is %zu bytes (>= 4 GiB): DSS on read disabled, one DSS pass per stage\n", c->tps * 8);
+      fprintf(stderr, "transport_se_hip: a scratch plane is %zu bytes (>= %zu): DSS on read disabled, one DSS pass per stage\n", c->tps * 8, plane_limit);
       said = true;
     }
     gor = false;
@@ -1284,6 +1322,10 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
     LAUNCH_CHECK();
     return 0;
   };
+  if (getenv("TSE_TEST_FAIL_REMAP")) {   // tests: this process's remap reports a negative layer thickness (one rank of several failing alone)
+    static const int one = 1;
+    HIPCHK(hipMemcpyAsync(c->bad, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
+  }
   if (prefetch && c->halo()) {
     const int nq = c->qsize * NLEV;
     hipStream_t cs = c->comm_stream;

@@ -154,13 +154,17 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
   double dpk[4], dv[4];
   const size_t lo = ((size_t)e * NLEV + kc) * 16 + j * 4;
   load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
+  // Q = Qdp * (1/dp): every kernel that forms element bounds (here, k_lap1, k_advance<1>, the emissions of k_dss_patch<1> and
+  // k_remap) multiplies by the reciprocal of dp, computed once per (element, level) -- so the cached bounds a step inherits from
+  // its predecessor's last kernel and the bounds recomputed here are the same bits (the reference divides, :764-775: <= 1 ulp
+  // in a limiter bound)
 #pragma unroll
-  for (int i = 0; i < 4; i++) dpk[i] = dpk[i] - rdt * dv[i];
+  for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
   for (int q = 0; q < qsize; q++) {
     double x[4];
     load4(Qn0 + (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, x);
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = x[i] / dpk[i];
+    for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
     double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     if (j == 0 && k < NLEV) {
@@ -471,7 +475,10 @@ __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0), int PSZ = 16 /* block shape (GIN != 0): Patch<PSZ> */>
-__global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
+#ifndef TSE_ADV2_WPE
+#define TSE_ADV2_WPE 1   // A/B: minimum waves per SIMD asked of the compiler for k_advance<2,3,.,16> (3 = the 168-register tier)
+#endif
+__global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3 && PSZ == 16) ? TSE_ADV2_WPE : 1) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
                                                           const double* __restrict__ dp, const double* __restrict__ divdp,
@@ -849,7 +856,11 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
   GatherRaw graw;
   gather_setup<PSZ>(RG, lds_, GA, pid);
   double dn[4] = {1, 1, 1, 1}, q0x[4] = {0, 0, 0, 0};
-  if (MODE == 1 && mn_out) load4(dpnext + ((size_t)e * NLEV + kc) * 16 + j * 4, dn);
+  if (MODE == 1 && mn_out) {   // 1/dp of the next step's stage 1 (the bounds are Qdp * (1/dp) everywhere: k_qminmax)
+    load4(dpnext + ((size_t)e * NLEV + kc) * 16 + j * 4, dn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) dn[i] = 1.0 / dn[i];
+  }
   auto fetch = [&](int q) {
     gather_issue(RG, GA, src, q, graw);
     if (MODE == 1) load4(Qn0 + (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, q0x);
@@ -882,7 +893,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
     if (MODE == 1 && mn_out) {
       double y[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) y[i] = cur.x[i] / dn[i];
+      for (int i = 0; i < 4; i++) y[i] = cur.x[i] * dn[i];
       cur.mn = quad_min(fmin(fmin(y[0], y[1]), fmin(y[2], y[3])));
       cur.mx = quad_max(fmax(fmax(y[0], y[1]), fmax(y[2], y[3])));
     }

@@ -139,8 +139,21 @@ contains
        if (msg(i) == c_null_char) exit
        text(i:i) = msg(i)
     enddo
-    call abortmp(where//': '//trim(text))
+    call seam_abort(where//': '//trim(text))
   end subroutine check
+
+  ! abortmp (parallel_mod.F90:274-287) writes its message to buffered stdout and then calls MPI_Abort, which loses it whenever
+  ! stdout is a pipe or a file; the message goes to stderr first (and both units are flushed)
+  ! and abortmp hands MPI_Abort an uninitialised error code (often 0: the launcher then reports success), so the job is ended
+  ! here with a defined one; abortmp stays behind it as the reference's own route
+  subroutine seam_abort(text)
+    character(len=*), intent(in) :: text
+    integer :: ierr
+    write(0,'(a)') ' cuda_mod_hip: ABORTING WITH ERROR: '//text
+    flush(0); flush(6)
+    call MPI_Abort(MPI_COMM_WORLD, 1, ierr)
+    call abortmp(text)
+  end subroutine seam_abort
 
   subroutine tic()
     call system_clock(t_c0)
@@ -181,10 +194,10 @@ contains
     ! hyperviscosity is the single constant-coefficient application of euler_step (prim_advection_mod.F90:796-826; no tracer
     ! subcycling, no variable / tensor coefficient: derivative_mod.F90:2438-2445), the remap is remap_Q_ppm with ghost-cell
     ! variant 0|1 or 2 (prim_advection_mod.F90:230-341).
-    if (qsplit /= 1) call abortmp('cuda_mod_init(hip): qsplit must be 1')
-    if (hypervis_subcycle_q /= 1) call abortmp('cuda_mod_init(hip): hypervis_subcycle_q must be 1')
-    if (hypervis_power /= 0 .or. hypervis_scaling /= 0) call abortmp('cuda_mod_init(hip): hypervis_power and hypervis_scaling must be 0')
-    if (vert_remap_q_alg < 0 .or. vert_remap_q_alg > 2) call abortmp('cuda_mod_init(hip): vert_remap_q_alg must be 0, 1 or 2')
+    if (qsplit /= 1) call seam_abort('cuda_mod_init(hip): qsplit must be 1')
+    if (hypervis_subcycle_q /= 1) call seam_abort('cuda_mod_init(hip): hypervis_subcycle_q must be 1')
+    if (hypervis_power /= 0 .or. hypervis_scaling /= 0) call seam_abort('cuda_mod_init(hip): hypervis_power and hypervis_scaling must be 0')
+    if (vert_remap_q_alg < 0 .or. vert_remap_q_alg > 2) call seam_abort('cuda_mod_init(hip): vert_remap_q_alg must be 0, 1 or 2')
     allocate(putm(8,nelemd), getm(8,nelemd), revm(8,nelemd))
     do ie = 1, nelemd
        putm(:,ie) = elem(ie)%desc%putmapP(1:8)
@@ -331,7 +344,7 @@ contains
     integer(c_size_t) :: s
     type(c_ptr) :: pdiv, peta, pomg
     call tic()
-    if (nets /= 1 .or. nete /= nelemd) call abortmp('euler_step_cuda(hip): needs NThreads=1 (nets:nete = 1:nelemd)')
+    if (nets /= 1 .or. nete /= nelemd) call seam_abort('euler_step_cuda(hip): needs NThreads=1 (nets:nete = 1:nelemd)')
     s = estride(elem)   ! every field lives in the same fixed-size element_t, so one stride serves all
     ! The CUDA seam stages elem%derived on every call (cuda_mod.F90:535-547, 564-586).  Nothing on the host changes vn0, dp,
     ! divdp, eta_dot_dpdn or omega_p between the three euler_step calls of a tracer step (prim_advection_mod.F90:614-637), and

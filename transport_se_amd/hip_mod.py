@@ -132,6 +132,12 @@ class HipMod:
         self.L.tse_boundary_layout(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def patch_layout(self):
+        """(patches that touch another rank, patches that do not) of the storage tiling"""
+        a, b = C.c_int(), C.c_int()
+        self.L.tse_patch_layout(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def invalidate_cache(self):
         self.L.tse_invalidate_cache(self.h)
 

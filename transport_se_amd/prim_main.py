@@ -187,6 +187,17 @@ def main(argv=None):
 
     from . import cube_mesh as cm
     from .driver import PrimRun
+    from .hip_mod import TseError
+    if os.environ.get("TSE_TEST_FAIL_REMAP_RANK") == str(rank):   # tests: this rank alone meets a negative layer thickness
+        os.environ["TSE_TEST_FAIL_REMAP"] = "1"
+
+    def abort_all(msg):
+        """abortmp (parallel_mod.F90:274-287): message, then every rank must end.  The failing rank exits non-zero at once -- it
+        must not enter another collective -- and the launcher (torch.distributed.run, mpiexec, srun) takes the other ranks down;
+        where a launcher does not, their watchdog (TSE_WATCHDOG_S) does."""
+        print(" %d ABORTING WITH ERROR: %s" % (rank, msg), flush=True)
+        print("prim_main: rank %d: %s" % (rank, msg), file=sys.stderr, flush=True)
+        os._exit(2)
     run = PrimRun(s["ne"], s["qsize"], test_case=s["test"], nu_q=s["nu_q"], tstep=s["tstep"], rsplit=s["rsplit"], rank=rank, world=world,
                   device=local, dist_mod=dist, torch_mod=torch, exchange=exchange, vert_remap_q_alg=s["vert_remap_q_alg"])
     hip, gid, nelem = run.hip, run.mine, run.nelem
@@ -218,7 +229,10 @@ def main(argv=None):
         if diag:
             f = s["statefreq"] * s["rsplit"] // np.gcd(s["statefreq"], s["rsplit"])
             stop = min(nsteps, (run.nstep // f + 1) * f)
-        np1 = run.run(stop - n)
+        try:
+            np1 = run.run(stop - n)
+        except TseError as ex:   # e.g. "negative layer thickness" (prim_advection_mod.F90:1323): the reference aborts the whole job there
+            abort_all("%s (tracer step %s)" % (ex, getattr(ex, "nstep", "?")))
         n = stop
         if diag and run.nstep % s["statefreq"] == 0 and run.nstep % s["rsplit"] == 0:
             ps_v = hip.fetch("ps_v", (gid.size, 4, 4))
