@@ -1315,7 +1315,7 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
     if (!w.nwork) return 0;
     auto go = [&](auto kern, int threads) {
       hipLaunchKernelGGL(kern, dim3(w.nwork), dim3(threads), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order);
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order, c->lvl_tmp);
     };
     if (nt == 1) { if (c->remap_alg2) go(k_remap<1, true>, REMAP_THREADS); else go(k_remap<1, false>, REMAP_THREADS); }
     else { if (c->remap_alg2) go(k_remap<2, true>, REMAP_THREADS / 2); else go(k_remap<2, false>, REMAP_THREADS / 2); }
@@ -1397,7 +1397,7 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
     auto go = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
                          c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
-                         (const int*)nullptr);
+                         (const int*)nullptr, c->lvl_tmp);
     };
     if (c->remap_alg2) go(k_remap<1, true>); else go(k_remap<1, false>);
     if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }

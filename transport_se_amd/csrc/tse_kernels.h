@@ -1026,55 +1026,71 @@ __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0
 }
 
 // ---------------------------------------------------------------------------------------------------
-// vertical_remap + remap_Q_ppm (prim_advection_mod.F90:1242-1330, 98-356).  Block = element.
-// Phase 1 (grid part, once per column): dp3d, ps_v, target dp, interface sums, bracket search kid/z2, the 10 PPM
-// grid coefficients per level -> LDS.  Phase 2: thread = (tracer q, column p) streams down the column keeping a
-// 5-cell window of cell means in registers (kid(k) >= k-1 by construction of the search, :160-166, so the
-// in-place update never overtakes the reads).
-constexpr int REMAP_THREADS = 512;   // 8 waves: 2 per SIMD
+// vertical_remap + remap_Q_ppm (prim_advection_mod.F90:1242-1330, 98-356).  Block = element, 4 waves; TWO blocks share a CU.
+// Phase 1 (grid part, once per column): dp3d, ps_v, target dp, interface sums, bracket search kid/z2, the PPM grid
+// coefficients per level -> LDS.  Phase 2: thread = (tracer q, column p) streams down the column keeping a 5-cell window of
+// cell means in registers (kid(k) >= k-1 by construction of the search, :160-166, so the in-place update never overtakes
+// the reads).
+// Everything the column loop reads is cut to < 80 KB of LDS, so that two elements fit a CU and one element's grid phase (serial
+// scans on 16 lanes, ~14 000 divisions) runs beside the other's column loop:
+//   * the ten grid coefficients of compute_ppm_grids (:221-260) enter the column arithmetic only through five combinations:
+//       da(j)  = c1 (c2 (a(j+1)-a(j)) + c3 (a(j)-a(j-1)))                       = e1 (a(j+1)-a(j)) + e2 (a(j)-a(j-1))
+//       ai(j)  = a(j) + c4 d + c5 (c6 (c7-c8) d - c9 dma(j+1) + c10 dma(j)),  d = a(j+1)-a(j)
+//              = a(j) + f3 d - f8 dma(j+1) + f9 dma(j)
+//     with e1 = c1 c2, e2 = c1 c3, f3 = c4 + c5 c6 (c7-c8), f8 = c5 c9, f9 = c5 c10 formed once per (level, column): 47 KB instead
+//     of 95 KB, five LDS reads and three flops less per level and tracer (products re-associated: relative 1e-16 per level);
+//   * dpo(kid(k)) is stored per NEW level with "kid(k) == k+1" in its sign bit (no kid array, no select of two dpo values);
+//   * 1/dp of the next step (bounds emission) goes through a global level field (rdp_g; an L1/L2-resident 9 KB per element);
+//   * the scratch of phase 1 (old interface pressures, hybrid-coefficient differences) lies where the coefficients go afterwards.
+// Measured (profiles/r03_ab_remap_two_blocks.txt): 16.5 -> 16.0 ms per launch at ne120/q35 -- the launch is bound by the vector
+// issue of the column loop (two waves per SIMD in both forms), not by the phases following one another.
+constexpr int REMAP_THREADS = 256;   // 4 waves: one per SIMD and element
 constexpr int REMAP_PF = 8;  // column loads kept in flight per thread
 static_assert(REMAP_PF % CL == 0, "a block of REMAP_PF levels holds whole chunks of the bounds layout");
-constexpr int REMAP_SEG_MAX = 8;   // at most this many tracers of an element go through segment tasks (LDS for their mass prefixes)
+constexpr int REMAP_SEG_MAX = 3;   // at most this many tracers of an element go through segment tasks (LDS for their mass prefixes)
 // tracers left over after whole rounds of `slots` tracer slots; more than REMAP_SEG_MAX of them take one more (partly idle) round
 __host__ __device__ inline int remap_left(int qsize, int slots, int nt) {
   const int left = qsize % slots;
   return nt == 1 && left <= REMAP_SEG_MAX ? left : 0;
 }
 struct RemapLds {
-  double ppmdx[NLEV + 2][10][16];  // [j][coef][p]
-  double dpo[NLEV + 4][16];        // index j+1, j = -1..NLEV+2
-  double rdpo[NLEV + 4][16];       // 1/dpo (the column loop multiplies instead of dividing)
-  double dpn[NLEV][16];            // 1 / derived%dp of the next step (only for the fused min/max emission)
+  double cd[NLEV + 2][2][16];      // [j][e1|e2][p], cell j = 0..NLEV+1 (stage 1 of compute_ppm)                      18.9 KB
+  double ca[NLEV + 1][3][16];      // [j][f3|f8|f9][p], interface j = 0..NLEV (stage 2)                               28.0 KB
+  double rdpo[NLEV + 4][16];       // 1/dpo, index j+1, j = -1..NLEV+2 (the column loop multiplies instead of dividing)
+  double dsel[NLEV + 4][16];       // phase 1: dpo, index j+1.  Column loop (lockstep form): row k-1 = dpo(kid(k)), negated where kid(k) == k+1
   double z2[NLEV][16];
-  double pio[NLEV + 2][16];        // index j-1, j = 1..NLEV+2
-  int kid[NLEV][16];
-  double dA[NLEV], dB[NLEV];       // hyai(k+1)-hyai(k), hybi(k+1)-hybi(k)
   double mpre[REMAP_SEG_MAX][NLEV / REMAP_PF - 1][16];   // segment tasks: mass of cells 1 .. 8s-1 of the leftover tracers' columns
+  unsigned char kid[NLEV][16];     // kid(k) (generic column loop)
   int slow;                        // some column has kid(k) outside {k, k+1}
+  // phase-1 scratch inside the coefficient arrays (dead before they are written)
+  __device__ double (*pio())[16] { return reinterpret_cast<double (*)[16]>(&cd[0][0][0]); }   // [NLEV + 2][16]: index j-1, j = 1..NLEV+2
+  __device__ double* dA() { return &ca[0][0][0]; }                                            // hyai(k+1)-hyai(k)
+  __device__ double* dB() { return &ca[0][0][0] + NLEV; }                                     // hybi(k+1)-hybi(k)
 };
+static_assert(2 * NLEV <= (NLEV + 1) * 3 * 16, "phase-1 scratch fits the coefficient arrays");
+static_assert(2 * sizeof(RemapLds) <= 160 * 1024, "two elements per CU");
 // The column arithmetic below is compiled WITHOUT implicit FMA contraction and spells its fused operations out: what the
 // compiler fuses on its own depends on which multiplies it happens to see in the same basic block -- in an unrolled block of
 // levels the product a = m/dp of the previous level, across a block boundary not -- so the rounding of a level would depend
 // on where in a block, a sweep or a segment task it is evaluated.  Written out, every level of every column is one fixed
 // sequence of roundings, whatever loop produces it (tests/test_gpu_parity.py: segment tasks against whole sweeps, bit for bit).
 #pragma clang fp contract(off)
-__device__ __forceinline__ double ppm_dma(double d0, double d1, double d2, double am, double a0, double ap) {
-  double da = d0 * fma(d1, ap - a0, d2 * (a0 - am));
-  double m = fmin(fabs(da), fmin(2. * fabs(a0 - am), 2. * fabs(ap - a0)));
+__device__ __forceinline__ double ppm_dma(double e1, double e2, double am, double a0, double ap) {
+  double da = fma(e1, ap - a0, e2 * (a0 - am));
+  double m = fmin(fabs(da), 2. * fmin(fabs(a0 - am), fabs(ap - a0)));   // minval(|da|, 2|a(j)-a(j-1)|, 2|a(j+1)-a(j)|): the doubling is exact
   double r = copysign(m, da);
   if ((ap - a0) * (a0 - am) <= 0.) r = 0.;
   return r;
 }
-// interface value between cells j and j+1 (compute_ppm stage 2, :295-303): aj + c3*(ajp-aj) + c4*(c5*(ajp-aj) - c8*dma(j+1) + c9*dma(j))
-__device__ __forceinline__ double ppm_ai(double c3, double c4, double c5, double c8, double c9, double aj, double ajp, double dmajp, double dmaj) {
-  const double d = ajp - aj;
-  return fma(c4, fma(c9, dmaj, fma(c5, d, -(c8 * dmajp))), fma(c3, d, aj));
+// interface value between cells j and j+1 (compute_ppm stage 2, :295-303) in the folded form: aj + f3*(ajp-aj) - f8*dma(j+1) + f9*dma(j)
+__device__ __forceinline__ double ppm_ai(double f3, double f8, double f9, double aj, double ajp, double dmajp, double dmaj) {
+  return fma(f9, dmaj, fma(-f8, dmajp, fma(f3, ajp - aj, aj)));
 }
 __device__ __forceinline__ double remap_dma_at(const RemapLds& S, int j, int p, double am, double a0, double ap) {
-  return ppm_dma(S.ppmdx[j][0][p], S.ppmdx[j][1][p], S.ppmdx[j][2][p], am, a0, ap);
+  return ppm_dma(S.cd[j][0][p], S.cd[j][1][p], am, a0, ap);
 }
 __device__ __forceinline__ double remap_ai_at(const RemapLds& S, int j, int p, double aj, double ajp, double dmajp, double dmaj) {
-  return ppm_ai(S.ppmdx[j][3][p], S.ppmdx[j][4][p], S.ppmdx[j][5][p], S.ppmdx[j][8][p], S.ppmdx[j][9][p], aj, ajp, dmajp, dmaj);
+  return ppm_ai(S.ca[j][0][p], S.ca[j][1][p], S.ca[j][2][p], aj, ajp, dmajp, dmaj);
 }
 // limited parabola of one cell from its mean a0 and interface values (compute_ppm stage 3, :309-331)
 __device__ __forceinline__ void remap_coefs(double al, double ar, double a0, double& c0, double& c1, double& c2) {
@@ -1105,7 +1121,7 @@ __device__ __forceinline__ void ppm_alg2(int cell, double a0, double& c0, double
 }
 template <bool ALG2>
 __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
-                                                   double* __restrict__ mn_out, double* __restrict__ mx_out) {
+                                                   double* __restrict__ mn_out, double* __restrict__ mx_out, const double* __restrict__ rdpg /* [k][p]: 1/dp of the next step */) {
   const int p = tid & 15;
   for (int q = tid >> 4; q < qsize; q += nthreads >> 4) {
     double* col = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
@@ -1153,12 +1169,12 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
       }
       double z1, zz2, z3;
       ppm_zterms(S.z2[k - 1][p], z1, zz2, z3);
-      double massn2 = fma(ppm_integ(c0, c1, c2, z1, zz2, z3), S.dpo[kk + 1][p], masso_kk);
+      double massn2 = fma(ppm_integ(c0, c1, c2, z1, zz2, z3), S.dsel[kk + 1][p] /* = dpo(kk): this loop keeps phase 1's dpo there */, masso_kk);
       const double qnew = massn2 - massn1;
       col[(size_t)(k - 1) * 16] = qnew;
       massn1 = massn2;
       if (mn_out) {   // element min/max of Q = Qdp/dp over the 16 columns (one DPP row) for the next step's stage 1
-        const double x = qnew * S.dpn[k - 1][p];
+        const double x = qnew * rdpg[(k - 1) * 16 + p];
         double mn = x, mx = x;
         mn = fmin(mn, dppq<0xB1>(mn)); mn = fmin(mn, dppq<0x4E>(mn)); mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
         mx = fmax(mx, dppq<0xB1>(mx)); mx = fmax(mx, dppq<0x4E>(mx)); mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
@@ -1186,7 +1202,8 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
 // then its REMAP_PF levels: the same values in the same order as a whole sweep produces.
 template <int NT, bool ALG2>
 __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
-                                                   double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink) {
+                                                   double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink,
+                                                   const double* __restrict__ rdpg /* [k][p]: 1/dp of the next step (bounds emission) */) {
   const int p = tid & 15, slots = (nthreads >> 4) * NT;
   // The level body below is free of branches and predicated stores, so that the 8 levels of an unrolled block form one
   // basic block and the scheduler can overlap the dependency chains of neighbouring levels.  A surplus tracer slot of the
@@ -1196,7 +1213,8 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   double *colw[NT], *mnp[NT], *mxp[NT];
   double pf[NT][REMAP_PF];
   double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
-  double xq[NT][CL];   // Q of the levels of the current chunk (fused bounds emission)
+  double xq[NT][CL];   // Qdp of the levels of the current chunk (fused bounds emission: times dnq = 1/dp of the next step, then min/max)
+  double dnq[CL];
   double* const dump_mn = sink + NLEV * 16;
   double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * qsize;
   auto aim = [&](int t, int qq, bool on) __attribute__((always_inline)) {
@@ -1228,9 +1246,9 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   };
   // one level; TAIL: the window may run into the mirrored ghost cells and the FIFO may run dry (the last two blocks of 8, and
   // every block of a segment task, whose kb differs from lane to lane)
-  const double *bp, *brdpo, *bdpo, *bz2, *bdpn; const int* bkid;   // per-block LDS bases
+  const double *bcd, *bca, *brdpo, *bds, *bz2;   // per-block LDS bases
   auto bases = [&](int kb) __attribute__((always_inline)) {
-    bp = &S.ppmdx[kb][0][p]; brdpo = &S.rdpo[kb][p]; bdpo = &S.dpo[kb][p]; bz2 = &S.z2[kb][p]; bdpn = &S.dpn[kb][p]; bkid = &S.kid[kb][p];
+    bcd = &S.cd[kb][0][p]; bca = &S.ca[kb][0][p]; brdpo = &S.rdpo[kb][p]; bds = &S.dsel[kb][p]; bz2 = &S.z2[kb][p];
   };
   auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl, auto reload_tag) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value, RELOAD = decltype(reload_tag)::value;   // RELOAD: keep the FIFO filled
@@ -1255,18 +1273,17 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
     // small compile-time immediates.  Indexed from the struct base, most of the 147 KB lie beyond the 64 KB an LDS
     // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
     const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
-    const double d0 = bp[(jdo * 10 + 0) * 16], d1 = bp[(jdo * 10 + 1) * 16], d2 = bp[(jdo * 10 + 2) * 16];
-    const double e3 = bp[(jao * 10 + 3) * 16], e4 = bp[(jao * 10 + 4) * 16], e567 = bp[(jao * 10 + 5) * 16],
-                 e8 = bp[(jao * 10 + 8) * 16], e9 = bp[(jao * 10 + 9) * 16];
-    const int kt = bkid[sl * 16];
-    const bool o = kt != k;   // kid(k) == k+1
-    const double dsel = o ? bdpo[(sl + 3) * 16] : bdpo[(sl + 2) * 16], dn = bdpn[sl * 16];
+    const double e1 = bcd[(jdo * 2 + 0) * 16], e2 = bcd[(jdo * 2 + 1) * 16];
+    const double f3 = bca[(jao * 3 + 0) * 16], f8 = bca[(jao * 3 + 1) * 16], f9 = bca[(jao * 3 + 2) * 16];
+    const double dss = bds[sl * 16];
+    const bool o = __double2hiint(dss) < 0;   // kid(k) == k+1 rides in the sign bit of dpo(kid(k))
+    const double dsel = fabs(dss);
     double z1, zz2, z3;
     ppm_zterms(bz2[sl * 16], z1, zz2, z3);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const double dmak2 = ppm_dma(d0, d1, d2, ak1[t], ak2[t], ak3[t]);
-      const double aik1 = ppm_ai(e3, e4, e567, e8, e9, ak1[t], ak2[t], dmak2, dmak1[t]);
+      const double dmak2 = ppm_dma(e1, e2, ak1[t], ak2[t], ak3[t]);
+      const double aik1 = ppm_ai(f3, f8, f9, ak1[t], ak2[t], dmak2, dmak1[t]);
       const double mo1 = masso[t] + mk[t];
       const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
       double c0, c1, c2;
@@ -1276,7 +1293,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       const double qnew = massn2 - massn1[t];
       colw[t][(size_t)(k - 1) * 16] = qnew;
       massn1[t] = massn2;
-      if (EMIT) xq[t][sl % CL] = qnew * dn;   // Q = Qdp/dp of the next step's stage 1; reduced over the columns by emit4
+      if (EMIT) xq[t][sl % CL] = qnew;        // times 1/dp of the next step's stage 1 and reduced over the columns by emit4
       masso[t] = mo1;
       ak[t] = ak1[t]; ak1[t] = ak2[t]; ak2[t] = ak3[t];
       mk[t] = mk1[t]; mk1[t] = mk2[t]; mk2[t] = mk3[t];
@@ -1291,7 +1308,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
     const bool b0 = p & 1, b1 = p & 2;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const double* x = xq[t];
+      const double x[CL] = {xq[t][0] * dnq[0], xq[t][1] * dnq[1], xq[t][2] * dnq[2], xq[t][3] * dnq[3]};   // Q = Qdp * (1/dp)
       const double s0 = b0 ? x[0] : x[2], s1 = b0 ? x[1] : x[3], k0 = b0 ? x[2] : x[0], k1 = b0 ? x[3] : x[1];
       const double r0 = dppq<0xB1>(s0), r1 = dppq<0xB1>(s1);
       const double n0 = fmin(k0, r0), n1 = fmin(k1, r1), m0 = fmax(k0, r0), m1 = fmax(k1, r1);
@@ -1308,6 +1325,10 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
     bases(kb);
 #pragma unroll
     for (int sl = 0; sl < REMAP_PF; sl++) {
+      if (decltype(emit_tag)::value && sl % CL == 0) {   // the chunk's 1/dp: loaded here, used four levels later
+#pragma unroll
+        for (int i = 0; i < CL; i++) dnq[i] = rdpg[(kb + sl + i) * 16 + p];
+      }
       level(tail_tag, emit_tag, kb, sl, reload_tag);
       if (sl % CL == CL - 1) { if (decltype(emit_tag)::value) emit4(kb, sl - (CL - 1)); __builtin_amdgcn_sched_barrier(0); }
     }
@@ -1382,29 +1403,32 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 #pragma clang fp contract(fast)   // (the default of the rest of the file)
 
 template <int NT, bool ALG2 = false>
-__global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double dt, double ps0, const double* __restrict__ hyai,
-                                                         const double* __restrict__ hybi, const double* __restrict__ dp,
-                                                         const double* __restrict__ divdp_proj, double* __restrict__ dp3d,
-                                                         double* __restrict__ ps_v, double* __restrict__ Q,
-                                                         int* __restrict__ bad, double* __restrict__ mn_out,
-                                                         double* __restrict__ mx_out, int force_generic, double* __restrict__ sink,
-                                                         const double* __restrict__ dp2 /* null: the target grid of vertical_remap
-                                                         (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */,
-                                                         const int* __restrict__ elist /* elements of this launch (null: 0..gridDim) */) {
+__global__ __launch_bounds__(REMAP_THREADS / NT, NT == 1 ? 2 : 1 /* <= 256 registers: two blocks per CU */) void k_remap(
+    int qsize, double dt, double ps0, const double* __restrict__ hyai, const double* __restrict__ hybi, const double* __restrict__ dp,
+    const double* __restrict__ divdp_proj, double* __restrict__ dp3d, double* __restrict__ ps_v, double* __restrict__ Q, int* __restrict__ bad,
+    double* __restrict__ mn_out, double* __restrict__ mx_out, int force_generic, double* __restrict__ sink,
+    const double* __restrict__ dp2 /* null: the target grid of vertical_remap (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */,
+    const int* __restrict__ elist /* elements of this launch (null: 0..gridDim) */,
+    double* __restrict__ rdp_g /* [e][k][p] work field: 1/dp of the next step, for the bounds emission (written and read by the same block) */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
   const int e = elist ? elist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+  double (*const pio)[16] = S.pio();
+  double* const dA = S.dA();
+  double* const dB = S.dB();
+  double (*const dpo)[16] = S.dsel;   // phase 1 keeps dpo (index j+1) where the column loop finds dpo(kid(k)) afterwards
+  double* const rdpg = rdp_g + (size_t)e * NLEV * 16;
   if (tid == 0) S.slow = force_generic;
   // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
   for (int w = tid; w < NLEV * 16; w += nthreads) {
     size_t o = (size_t)e * NLEV * 16 + w;
     double d = dp[o] - dt * divdp_proj[o];
     dp3d[o] = d;
-    S.dpo[(w >> 4) + 2][w & 15] = d;
-    S.dpn[w >> 4][w & 15] = 1.0 / dp[o];   // Q = Qdp * (1/dp), as k_advance forms its local bounds
+    dpo[(w >> 4) + 2][w & 15] = d;
+    if (mn_out) rdpg[w] = 1.0 / dp[o];   // Q = Qdp * (1/dp), as every kernel forms its bounds (k_qminmax)
     if (d < 0) atomicOr(bad, 1);
   }
-  if (tid < NLEV) { S.dA[tid] = hyai[tid + 1] - hyai[tid]; S.dB[tid] = hybi[tid + 1] - hybi[tid]; }
+  if (tid < NLEV) { dA[tid] = hyai[tid + 1] - hyai[tid]; dB[tid] = hybi[tid + 1] - hybi[tid]; }
   __syncthreads();
   if (tid < 16) {
     // The column scans keep the reference's serial order (their roundings are part of the result), so 16 lanes do them; what
@@ -1416,19 +1440,19 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     constexpr int SB = 12;
     static_assert(NLEV % SB == 0, "scan batches");
     double run = 0.0;
-    S.pio[0][p] = 0.0;
+    pio[0][p] = 0.0;
     for (int kb = 0; kb < NLEV; kb += SB) {
       double d[SB];
 #pragma unroll
-      for (int i = 0; i < SB; i++) d[i] = S.dpo[kb + i + 2][p];
+      for (int i = 0; i < SB; i++) d[i] = dpo[kb + i + 2][p];
 #pragma unroll
-      for (int i = 0; i < SB; i++) { run = run + d[i]; S.pio[kb + i + 1][p] = run; }
+      for (int i = 0; i < SB; i++) { run = run + d[i]; pio[kb + i + 1][p] = run; }
     }
     const double pio_prev = run;
     const double ps = fma(hyai[0], ps0, run);
     ps_v[(size_t)e * 16 + p] = ps;
-    S.pio[NLEV + 1][p] = pio_prev + 1.;
-    for (int k = 1; k <= 2; k++) { S.dpo[2 - k][p] = S.dpo[k + 1][p]; S.dpo[NLEV + k + 1][p] = S.dpo[NLEV + 2 - k][p]; }
+    pio[NLEV + 1][p] = pio_prev + 1.;
+    for (int k = 1; k <= 2; k++) { dpo[2 - k][p] = dpo[k + 1][p]; dpo[NLEV + k + 1][p] = dpo[NLEV + 2 - k][p]; }
     // new-grid interface pressures pin(k+1) (serial sum, as the reference's :150-158), parked in z2's slot until the
     // bracket search below replaces them
     double pin = 0.0;
@@ -1439,7 +1463,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
         for (int i = 0; i < SB; i++) d[i] = dp2[((size_t)e * NLEV + kb + i) * 16 + p];
       } else {
 #pragma unroll
-        for (int i = 0; i < SB; i++) d[i] = fma(S.dA[kb + i], ps0, __dmul_rn(S.dB[kb + i], ps));   // dA*ps0 + dB*ps, one rounding of the sum
+        for (int i = 0; i < SB; i++) d[i] = fma(dA[kb + i], ps0, __dmul_rn(dB[kb + i], ps));   // dA*ps0 + dB*ps, one rounding of the sum
       }
 #pragma unroll
       for (int i = 0; i < SB; i++) {
@@ -1471,37 +1495,62 @@ __global__ __launch_bounds__(REMAP_THREADS / NT) void k_remap(int qsize, double 
     const int k = (w >> 4) + 1, p = w & 15;
     const double pin_k1 = S.z2[k - 1][p];
     int kk = k;
-    while (S.pio[kk - 1][p] <= pin_k1) kk++;
+    while (pio[kk - 1][p] <= pin_k1) kk++;
     kk--;
     if (kk == NLEV + 1) kk = NLEV;
-    S.kid[k - 1][p] = kk;
+    S.kid[k - 1][p] = (unsigned char)kk;
     if (kk != k && kk != k + 1) S.slow = 1;   // a displacement of more than one layer: this element takes the generic loop
-    S.z2[k - 1][p] = (pin_k1 - (S.pio[kk - 1][p] + S.pio[kk][p]) * 0.5) / S.dpo[kk + 1][p];
+    S.z2[k - 1][p] = (pin_k1 - (pio[kk - 1][p] + pio[kk][p]) * 0.5) / dpo[kk + 1][p];
   }
-  // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260), one (j,p) per work item
-  for (int w = tid; w < (NLEV + 4) * 16; w += nthreads) S.rdpo[w >> 4][w & 15] = 1.0 / S.dpo[w >> 4][w & 15];
+  __syncthreads();   // pio, dA, dB are dead: the coefficients go where they were
+  // ---- phase 1b: grid coefficients (compute_ppm_grids, :221-260) in the folded form the column loop uses, one (j,p) per work item
+  for (int w = tid; w < (NLEV + 4) * 16; w += nthreads) S.rdpo[w >> 4][w & 15] = 1.0 / dpo[w >> 4][w & 15];
   for (int w = tid; w < (NLEV + 2) * 16; w += nthreads) {
     const int jj = w >> 4, p = w & 15;  // jj = j, j = 0..NLEV+1
-#define DX(j) S.dpo[(j) + 1][p]
-    S.ppmdx[jj][0][p] = DX(jj) / (DX(jj - 1) + DX(jj) + DX(jj + 1));
-    S.ppmdx[jj][1][p] = (2. * DX(jj - 1) + DX(jj)) / (DX(jj + 1) + DX(jj));
-    S.ppmdx[jj][2][p] = (DX(jj) + 2. * DX(jj + 1)) / (DX(jj - 1) + DX(jj));
+#define DX(j) dpo[(j) + 1][p]
+    const double c1 = DX(jj) / (DX(jj - 1) + DX(jj) + DX(jj + 1));
+    S.cd[jj][0][p] = c1 * ((2. * DX(jj - 1) + DX(jj)) / (DX(jj + 1) + DX(jj)));
+    S.cd[jj][1][p] = c1 * ((DX(jj) + 2. * DX(jj + 1)) / (DX(jj - 1) + DX(jj)));
     if (jj <= NLEV) {
-      S.ppmdx[jj][3][p] = DX(jj) / (DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][4][p] = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
-      // (:255-257) the three factors of the curvature term only ever appear as c5*(c6 - c7), a level-only product that the
-      // reference evaluates first (left to right): stored once instead of three coefficients
-      S.ppmdx[jj][5][p] = ((2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1))) *
+      const double c4 = DX(jj) / (DX(jj) + DX(jj + 1));
+      const double c5 = 1. / (DX(jj - 1) + DX(jj) + DX(jj + 1) + DX(jj + 2));
+      // (:255-257) c6*(c7 - c8), evaluated as the reference does (left to right)
+      const double c678 = ((2. * DX(jj + 1) * DX(jj)) / (DX(jj) + DX(jj + 1))) *
                           ((DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1)) - (DX(jj + 2) + DX(jj + 1)) / (2. * DX(jj + 1) + DX(jj)));
-      S.ppmdx[jj][8][p] = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
-      S.ppmdx[jj][9][p] = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
+      const double c9 = DX(jj) * (DX(jj - 1) + DX(jj)) / (2. * DX(jj) + DX(jj + 1));
+      const double c10 = DX(jj + 1) * (DX(jj + 1) + DX(jj + 2)) / (DX(jj) + 2. * DX(jj + 1));
+      S.ca[jj][0][p] = c4 + c5 * c678;
+      S.ca[jj][1][p] = c5 * c9;
+      S.ca[jj][2][p] = c5 * c10;
     }
 #undef DX
   }
   __syncthreads();
   // ---- phase 2: data part
-  if (S.slow) remap_columns_generic<ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out);
-  else remap_columns_fast<NT, ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink);
+  if (S.slow) { remap_columns_generic<ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, rdpg); return; }
+  {
+    // dpo -> dpo(kid(k)) per new level, in place: read first, write after a barrier (a row is read by the two levels above it)
+    constexpr int PER = (NLEV * 16 + REMAP_THREADS / NT - 1) / (REMAP_THREADS / NT);
+    double v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int w = tid + i * nthreads;
+      v[i] = 0.0;
+      if (w < NLEV * 16) {
+        const int k = (w >> 4) + 1, p = w & 15, kk = S.kid[k - 1][p];
+        const double d = dpo[kk + 1][p];
+        v[i] = kk == k ? d : -d;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int w = tid + i * nthreads;
+      if (w < NLEV * 16) S.dsel[w >> 4][w & 15] = v[i];
+    }
+    __syncthreads();
+  }
+  remap_columns_fast<NT, ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink, rdpg);
 }
 
 // ---------------------------------------------------------------------------------------------------
