@@ -9,8 +9,9 @@ def short(n):
     if not m:
         return None
     t = (m.group(2) or "").replace(" ", "").replace("true", "1").replace("false", "0")
-    if m.group(1) == "k_advance" and t.count(",") == 2:
-        t = t[:t.rindex(",")] + ">"
+    if m.group(1) == "k_advance" and t.count(",") >= 2:
+        parts = t[1:-1].split(",")            # <RHS, GIN, DB[, PSZ]>: drop the DB flag, keep the block shape
+        t = "<" + ",".join(parts[:2] + parts[3:]) + ">"
     return m.group(1) + t
 
 d, ne, qsize, ngpu, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]

@@ -1045,7 +1045,11 @@ __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0
 // Measured (profiles/r03_ab_remap_two_blocks.txt): 16.5 -> 16.0 ms per launch at ne120/q35 -- the launch is bound by the vector
 // issue of the column loop (two waves per SIMD in both forms), not by the phases following one another.
 constexpr int REMAP_THREADS = 256;   // 4 waves: one per SIMD and element
-constexpr int REMAP_PF = 8;  // column loads kept in flight per thread
+#ifndef TSE_REMAP_PF
+#define TSE_REMAP_PF 8
+#endif
+constexpr int REMAP_PF = TSE_REMAP_PF;  // column loads kept in flight per thread = levels per unrolled block = levels per segment task
+static_assert(NLEV % REMAP_PF == 0, "whole blocks");
 static_assert(REMAP_PF % CL == 0, "a block of REMAP_PF levels holds whole chunks of the bounds layout");
 constexpr int REMAP_SEG_MAX = 3;   // at most this many tracers of an element go through segment tasks (LDS for their mass prefixes)
 // tracers left over after whole rounds of `slots` tracer slots; more than REMAP_SEG_MAX of them take one more (partly idle) round
