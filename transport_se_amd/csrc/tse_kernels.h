@@ -1254,17 +1254,39 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   auto bases = [&](int kb) __attribute__((always_inline)) {
     bcd = &S.cd[kb][0][p]; bca = &S.ca[kb][0][p]; brdpo = &S.rdpo[kb][p]; bds = &S.dsel[kb][p]; bz2 = &S.z2[kb][p];
   };
+  // The level-only LDS operands of a level (two dma coefficients, three interface coefficients, dpo(kid) with the kid bit, z2,
+  // 1/dpo of the cell entering the window) are fetched ONE LEVEL AHEAD: a level starts with its operands in registers and
+  // issues the next level's reads before it computes, so no wave parks behind an LDS latency at the top of every level (with two
+  // waves per SIMD nothing else covered those: 47 % of the wave cycles were waits).  Rows are addressed relative to the
+  // per-block bases (bcd = &cd[kb][0][p] etc., set up once per block): the offsets are small compile-time immediates, also for
+  // the first level of the NEXT block (sl + 1 == REMAP_PF), which is just the next row.
+  struct LevelOps { double e1, e2, f3, f8, f9, dss, z2, rr; };
+  LevelOps nxt;
+  auto fetch = [&](auto tail_tag, int kb, int sl) __attribute__((always_inline)) -> LevelOps {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int k = kb + sl + 1;
+    LevelOps v{0., 0., 0., 0., 0., 0., 0., 0.};
+    if (TAIL && k > NLEV) return v;   // (the level after the last one)
+    const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
+    v.e1 = bcd[(jdo * 2 + 0) * 16]; v.e2 = bcd[(jdo * 2 + 1) * 16];
+    v.f3 = bca[(jao * 3 + 0) * 16]; v.f8 = bca[(jao * 3 + 1) * 16]; v.f9 = bca[(jao * 3 + 2) * 16];
+    v.dss = bds[sl * 16];
+    v.z2 = bz2[sl * 16];
+    if (!TAIL || k + 3 <= NLEV) v.rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1], r = k + 3
+    return v;
+  };
   auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl, auto reload_tag) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value, RELOAD = decltype(reload_tag)::value;   // RELOAD: keep the FIFO filled
     const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
+    const LevelOps c = nxt;
+    nxt = fetch(tail_tag, kb, sl + 1);
     double ak3[NT], mk3[NT];
     if (!TAIL || r <= NLEV) {
-      const double rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1]
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         mk3[t] = pf[t][sl];
         if (RELOAD && (!TAIL || r + REMAP_PF <= NLEV)) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
-        ak3[t] = mk3[t] * rr;
+        ak3[t] = mk3[t] * c.rr;
       }
     } else {
 #pragma unroll
@@ -1273,21 +1295,14 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
         ak3[t] = r == NLEV + 1 ? ak2[t] : ak[t];
       }
     }
-    // LDS reads relative to per-block bases (bp = &ppmdx[kb][0][p] etc., set up once per 8 levels): the offsets are then
-    // small compile-time immediates.  Indexed from the struct base, most of the 147 KB lie beyond the 64 KB an LDS
-    // instruction offset can reach, and the ~180 lane addresses the compiler hoists out of the loop for it end up spilled.
-    const int jdo = !TAIL || k + 2 <= NLEV + 1 ? sl + 3 : NLEV + 1 - kb, jao = !TAIL || k + 1 <= NLEV ? sl + 2 : NLEV - kb;   // last level: unused
-    const double e1 = bcd[(jdo * 2 + 0) * 16], e2 = bcd[(jdo * 2 + 1) * 16];
-    const double f3 = bca[(jao * 3 + 0) * 16], f8 = bca[(jao * 3 + 1) * 16], f9 = bca[(jao * 3 + 2) * 16];
-    const double dss = bds[sl * 16];
-    const bool o = __double2hiint(dss) < 0;   // kid(k) == k+1 rides in the sign bit of dpo(kid(k))
-    const double dsel = fabs(dss);
+    const bool o = __double2hiint(c.dss) < 0;   // kid(k) == k+1 rides in the sign bit of dpo(kid(k))
+    const double dsel = fabs(c.dss);
     double z1, zz2, z3;
-    ppm_zterms(bz2[sl * 16], z1, zz2, z3);
+    ppm_zterms(c.z2, z1, zz2, z3);
 #pragma unroll
     for (int t = 0; t < NT; t++) {
-      const double dmak2 = ppm_dma(e1, e2, ak1[t], ak2[t], ak3[t]);
-      const double aik1 = ppm_ai(f3, f8, f9, ak1[t], ak2[t], dmak2, dmak1[t]);
+      const double dmak2 = ppm_dma(c.e1, c.e2, ak1[t], ak2[t], ak3[t]);
+      const double aik1 = ppm_ai(c.f3, c.f8, c.f9, ak1[t], ak2[t], dmak2, dmak1[t]);
       const double mo1 = masso[t] + mk[t];
       const double al = o ? aik[t] : aikm1[t], ar = o ? aik1 : aik[t], a0 = o ? ak1[t] : ak[t], ms = o ? mo1 : masso[t];
       double c0, c1, c2;
@@ -1350,6 +1365,8 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 #pragma unroll
     for (int t = 0; t < NT; t++) { const bool on = q0 + t < qsize; aim(t, on ? q0 + t : qsize - 1, on); }
     prime_top();
+    bases(0);
+    nxt = fetch(std::false_type{}, 0, 0);   // the first level's operands
     if (mn_out) column(std::true_type{});
     else column(std::false_type{});
   }
@@ -1389,10 +1406,13 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
           double* const w = colw[0];
           colw[0] = sink + p;
           bases(kb0 - REMAP_PF);
+          nxt = fetch(std::true_type{}, kb0 - REMAP_PF, REMAP_PF - 1);
           level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
           colw[0] = w;
         } else {
           prime_top();
+          bases(0);
+          nxt = fetch(std::false_type{}, 0, 0);
         }
       }
       __syncthreads();   // (waits for the loads, too)
