@@ -202,7 +202,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   }
   memcpy(c->D.d, a->Dvv, sizeof c->D.d);
   { std::vector<double> dv(a->Dvv, a->Dvv + 16); if (upload(&c->dvv_d, dv)) return 1; }
-  HIPCHK(hipStreamCreate(&c->stream));
+  HIPCHK(hipStreamCreate(&c->stream));   // blocking w.r.t. the legacy default stream: see the note above split_stage
   const int n = a->nelemd;
   std::vector<double> h;
   gather_strided(h, a->Dinv, a->Dinv_stride, n, 64);
@@ -1132,7 +1132,11 @@ int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
 // the stage, so the halo travels over xGMI while the interior elements are computed; the compute stream waits for it
 // only before the next stage's first launch.  With an RCCL communicator nothing blocks the host.  With the callback
 // form of the seam the host has to drain the packs and run the callback; that is done after the interior launch has
-// been queued, so the overlap is kept there too.
+// been queued.  Whether the exchange then overlaps the interior launch depends on the callback: one that moves the slots on
+// streams of its own (or over MPI from host memory) does; the Python callbacks of driver.HaloExchange copy on the legacy
+// default stream, which waits for this (blocking) compute stream -- their exchange runs behind the interior launch.  (The
+// compute stream stays a blocking stream on purpose: the synchronous hipMemcpy / hipMemset calls of the set-up and of the
+// operator-level entry points are ordered against it by the default-stream rule.)
 static hipEvent_t next_sync_event(tse_ctx* c) {
   hipEvent_t e = c->sync_events[c->sync_next];
   c->sync_next = (c->sync_next + 1) % c->sync_events.size();
