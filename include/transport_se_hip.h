@@ -112,8 +112,8 @@ int tse_comm_info(tse_ctx *ctx, int *rank, int *nranks);
 int tse_comm_abort(tse_ctx *ctx);
 /* number of local elements that touch another rank (computed first in every stage) and that do not */
 int tse_boundary_layout(tse_ctx *ctx, int *n_boundary, int *n_interior);
-/* the same in patches (the blocks of the DSS-on-read kernels; the rank-boundary elements are grouped into thin patches of their own,
- * so that the first launch of a stage stays a small fraction of the whole) */
+/* the same in patches (the blocks of the DSS-on-read kernels): the first launch of every stage covers the boundary patches.
+ * With TSE_BOUNDARY_STRIPS=1 the rank-boundary elements are grouped into patches of their own (a two-deep band), which halves it. */
 int tse_patch_layout(tse_ctx *ctx, int *np_boundary, int *np_interior);
 
 /* Optional: declare the host's element array (elem(1) .. elem(nelemd), contiguous, alive until tse_finalize).  It is page-locked

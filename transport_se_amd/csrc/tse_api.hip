@@ -365,8 +365,11 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     std::vector<char> isb(n, 0);   // elements that touch another rank
     for (const int2& q : send_src) isb[q.x] = 1;
     for (const int2& q : mm_src) isb[q.x] = 1;
-    // TSE_BOUNDARY_STRIPS=0: no thin patches along the rank boundary (A/B; the tiling then is the single-rank one everywhere)
-    const bool strips = !(getenv("TSE_BOUNDARY_STRIPS") && atoi(getenv("TSE_BOUNDARY_STRIPS")) == 0);
+    // TSE_BOUNDARY_STRIPS=1: rank-boundary elements in patches of their own (below).  Off by default: on 8 ranks of ne120 it halves
+    // the first launch of a stage (25.8 -> 11.8 % of the patches) but the ragged tiling behind the band costs 3 % of a rank's
+    // step (12.6 -> 13.0 ms in the loopback rehearsal, profiles/r03_ab_boundary_bands.txt), and the first launch only matters
+    // where an exchange outlasts the interior launch -- 0.7 ms of xGMI transfer against 1.3-2.2 ms of interior work here.
+    const bool strips = getenv("TSE_BOUNDARY_STRIPS") && atoi(getenv("TSE_BOUNDARY_STRIPS")) != 0;
     auto build = [&](int psz, std::vector<std::vector<int>>& patches, std::vector<int>& pid) {
       const int pw = psz / 4, nrmax = patch_nrmax(psz);
       pid.assign(n, -1);
@@ -393,29 +396,41 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
         std::sort(refs.begin(), refs.end());
         return (int)(std::unique(refs.begin(), refs.end()) - refs.begin());
       };
-      // Rank-boundary elements first, as THIN patches: a stage's first launch covers the patches that own a column of a send slot
-      // (split_stage), and with the regular tiling a 4 x 4 patch is such a patch as soon as one of its elements is -- a quarter of
-      // all patches on 8 ranks, for 6 % of the elements.  So the boundary elements are strung together along the boundary
-      // (element by element over the 8-neighbourhood, no interior element joins), as many per patch as the halo ring and the
-      // element ring allow: about ten (a 1 x 10 strip has a ring of 92), and the first launch shrinks to a tenth of the patches.
+      // Rank-boundary elements first, as patches of their own: a stage's first launch covers the patches that own a column of a
+      // send slot (split_stage), and with the regular tiling a 4 x 4 patch is such a patch as soon as one of its elements is -- a
+      // quarter of all patches on 8 ranks, for 6 % of the elements.  So up to half a patch of boundary elements is strung together
+      // along the boundary (element by element over the 8-neighbourhood), and the patch is then filled with the elements right
+      // behind them (edge neighbours of its members), as far as the halo ring and the element ring allow: a two-deep band along the
+      // rank boundary, full patches (strips of boundary elements alone left a third of the lanes empty and cost 6 % of a step),
+      // and a first launch of about twice the boundary elements' share.
       if (strips) {
-        const int maxlen = psz;
+        auto try_add = [&](std::vector<int>& cand, int me, int el) {
+          pid[el] = me; cand.push_back(el);
+          if (ring_size(cand, me) <= nrmax && ering_size(cand, me) <= NER) return true;
+          pid[el] = -1; cand.pop_back();
+          return false;
+        };
         for (int seed = 0; seed < n; seed++) {
           if (!isb[seed] || pid[seed] >= 0) continue;
           const int me = (int)patches.size();
           std::vector<int> cand{seed};
           pid[seed] = me;
           bool grew = true;
-          while (grew && (int)cand.size() < maxlen) {
+          while (grew && (int)cand.size() < psz / 2) {   // the chain of boundary elements
             grew = false;
-            // the next link of the chain: an unassigned boundary element next to the most recently added one, else next to any
             for (int back = (int)cand.size() - 1; back >= 0 && !grew; back--)
               for (int d = 0; d < 8 && !grew; d++) {
                 const int nb = nbr[cand[back] * 8 + d];
-                if (nb < 0 || !isb[nb] || pid[nb] >= 0) continue;
-                pid[nb] = me; cand.push_back(nb);
-                if (ring_size(cand, me) <= nrmax && ering_size(cand, me) <= NER) grew = true;
-                else { pid[nb] = -1; cand.pop_back(); }
+                if (nb >= 0 && isb[nb] && pid[nb] < 0) grew = try_add(cand, me, nb);
+              }
+          }
+          grew = true;
+          while (grew && (int)cand.size() < psz) {       // the elements behind it
+            grew = false;
+            for (size_t i = 0; i < cand.size() && !grew; i++)
+              for (int d = 0; d < 4 && !grew; d++) {
+                const int nb = nbr[cand[i] * 8 + d];
+                if (nb >= 0 && pid[nb] < 0) grew = try_add(cand, me, nb);
               }
           }
           patches.push_back(cand);

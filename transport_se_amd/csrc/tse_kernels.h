@@ -265,7 +265,8 @@ __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qs
 // plist/npwork: the patches this launch walks (nullptr: patches 0..npwork).  A multi-rank step launches every slab kernel
 // twice: first over the patches (plain kernels: elements, order/nwork) that touch another rank, so that their halo can travel
 // while the second launch computes the interior (tse_api.hip).
-constexpr int NER = 32;            // elements around a patch whose bounds the stage-3 kernel reads (full 4x4, 6x4, 8x4 patches: 20, 24, 28)
+constexpr int NER = 48;            // elements around a patch whose bounds the stage-3 kernel reads (full 4x4, 6x4, 8x4 patches: 20, 24, 28; a two-deep band
+                                   // along a rank boundary: every received (element, direction) pair is an entry of its own, about 40)
 struct GatherArgs {
   Scr S;
   const int* slot_of;              // element -> slot of the scratch layout
