@@ -121,3 +121,17 @@ def test_bfb_across_rank_counts():
         qn, dn = _run(world)
         assert np.array_equal(qn, q1), "Qdp differs between 1 and %d ranks" % world
         assert np.array_equal(dn, d1)
+
+
+@pytest.mark.parametrize("shape", ["16,16,16,16", "32,32,32,32", "24,16,32,24"])
+def test_bfb_with_boundary_bands_and_other_block_shapes(monkeypatch, shape):
+    """the tilings are pure scheduling: rank-boundary elements in patches of their own (TSE_BOUNDARY_STRIPS=1: chains along the boundary
+    filled with the elements behind them, any shape the halo-ring and element-ring tables allow) and 6x4 / 8x4 blocks for the
+    DSS-on-read kernels must leave every bit where the regular 4x4 tiling on one rank puts it"""
+    ref5 = _run(1, ne=5)          # default tiling, one rank
+    ref4 = _run(1)
+    monkeypatch.setenv("TSE_BOUNDARY_STRIPS", "1")
+    monkeypatch.setenv("TSE_PATCH_SHAPE", shape)
+    for world, ne, ref in ((4, 5, ref5), (3, None, ref4)):
+        qn, dn = _run(world, ne=ne)
+        assert np.array_equal(qn, ref[0]) and np.array_equal(dn, ref[1]), (world, ne, shape)
