@@ -69,6 +69,26 @@ __global__ __launch_bounds__(256) void k_mix_blk(size_t n, const double2* __rest
   }
 }
 
+// The access shape of k_dss_patch on the reference's [e][q][k][p] layout: a block = 16 elements x PIECE contiguous bytes (its levels of one
+// tracer), one tracer after the other (9216 B further on), the 18 chunks of an element handled by other blocks at other times; read one
+// such stream, write another.  PIECE = 512 is the kernel's shape (4 levels); larger pieces = more levels per block.
+template <int PIECE>
+__global__ __launch_bounds__(256) void k_pieces_rw(int nelem, int qsize, const char* __restrict__ in, char* __restrict__ out) {
+  constexpr int LPP = PIECE / 16, EPB = 256 / LPP;               // lanes per piece, elements per block
+  constexpr int NCH = 9216 / PIECE;                              // pieces per (element, tracer)
+  const int nblk_e = nelem / EPB;
+  for (int b = blockIdx.x; b < nblk_e * NCH; b += gridDim.x) {
+    const int ch = b / nblk_e, eb = b - ch * nblk_e;             // chunk-major walk, as the kernels do
+    if ((int)threadIdx.x >= EPB * LPP) continue;                  // (pieces that do not fill the block)
+    const int e = eb * EPB + threadIdx.x / LPP, l = threadIdx.x % LPP;
+    size_t off = (size_t)e * qsize * 9216 + (size_t)ch * PIECE + l * 16;
+    for (int q = 0; q < qsize; q++, off += 9216) {
+      const double2 v = *reinterpret_cast<const double2*>(in + off);
+      *reinterpret_cast<double2*>(out + off) = make_double2(v.x + 1.0, v.y);
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   const size_t bytes = (size_t)(argc > 1 ? atoi(argv[1]) : 8) << 30;
   char* buf; double* out;
@@ -118,6 +138,20 @@ int main(int argc, char** argv) {
       mix("k_mix<2> 512 blocks", 2, [&] { hipLaunchKernelGGL(k_mix<2>, dim3(512), blk, 0, 0, n, in, o); });
       mix("k_mix<2> 2048 blocks", 2, [&] { hipLaunchKernelGGL(k_mix<2>, dim3(2048), blk, 0, 0, n, in, o); });
     }
+  }
+  if (bytes >= ((size_t)8 << 30)) {
+    // 3.5 GB per stream: 10 800 elements x 35 tracers x 9216 B
+    const int nelem = 10800, qsize = 35;
+    const size_t fb = (size_t)nelem * qsize * 9216;
+    auto rw = [&](const char* name, auto launch) {
+      launch(); CK(hipDeviceSynchronize());
+      CK(hipEventRecord(a)); for (int r = 0; r < 3; r++) launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 3;
+      printf("%-34s %8.3f ms  %7.1f GB/s (read + write of %.1f GB each)\n", name, ms, 2.0 * fb / ms / 1e6, fb / 1e9);
+    };
+    rw("k_pieces_rw<512>  (4 levels)", [&] { hipLaunchKernelGGL(k_pieces_rw<512>, dim3(256 * 8), blk, 0, 0, nelem, qsize, (const char*)buf, buf + ((size_t)4 << 30)); });
+    rw("k_pieces_rw<1024> (8 levels)", [&] { hipLaunchKernelGGL(k_pieces_rw<1024>, dim3(256 * 8), blk, 0, 0, nelem, qsize, (const char*)buf, buf + ((size_t)4 << 30)); });
+    rw("k_pieces_rw<3072> (24 levels)", [&] { hipLaunchKernelGGL(k_pieces_rw<3072>, dim3(256 * 8), blk, 0, 0, nelem, qsize, (const char*)buf, buf + ((size_t)4 << 30)); });
   }
   return 0;
 }
