@@ -189,13 +189,17 @@ int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
 int tse_element_mass(tse_ctx *ctx, int nt, double *out);
 
 /* ---- introspection for tests and the benchmark harness ---- */
-/* device pointers of internal fields: "qdp" [2][nelemd][qsize][nlev][16], "vn0", "dp", "divdp", "divdp_proj",
+/* device pointers of internal fields: "qdp1", "qdp2" [nelemd][qsize][nlev][16] (the two time levels are two allocations), "vn0", "dp", "divdp", "divdp_proj",
  * "eta_dot_dpdn", "omega_p", "dp3d", "ps_v", "qmin", "qmax", "sendbuf", "recvbuf" */
 void *tse_device_ptr(tse_ctx *ctx, const char *name, size_t *nbytes);
 /* accumulated HIP-event time (ms) and launch count of a named kernel group since the last reset; names:
  * "advance" (= "advance0" + "advance1" + "advance2", the three RK stages), "dss", "lap", "minmax", "remap", "level", "dcmip", "avg" */
 int tse_kernel_time(tse_ctx *ctx, const char *name, double *ms, long *launches);
 int tse_timing(tse_ctx *ctx, int enable); /* enable/disable + reset per-kernel event timing */
+/* where the five tracer-sized fields were placed (tse_init times a streaming write into up to TSE_PLACEMENT, default 7, field-sized
+ * chunks and keeps the five fastest: device memory is not uniform for writes): number of candidates probed (0: no
+ * choice was made), their write rates in GB/s in allocation order, and the indices of the five that became T, Qdp(1), Qdp(2), B, C */
+int tse_placement(tse_ctx *ctx, int *ncand, double *write_gbs /* [8] */, int *chosen /* [5] */);
 int tse_halo_layout(tse_ctx *ctx, int *ncol_send, int *ncol_recv);
 /* per-slot entry counts of the kind-1 (min/max) exchange, in send-slot / recv-slot order */
 int tse_halo_minmax_layout(tse_ctx *ctx, int *send_len, int *recv_len);

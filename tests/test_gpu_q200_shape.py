@@ -45,7 +45,7 @@ def test_ne42_q200_full_sphere_properties(monkeypatch):
     run = PrimRun(ne, q, test_case=1)
     hip, n = run.hip, run.nelem
     dt = run.tstep
-    Q = _dev_tensor(torch, hip.device_ptr("qdp")[0], (2, n, q, 72, 16))
+    Q = [_dev_tensor(torch, hip.device_ptr("qdp%d" % tl)[0], (n, q, 72, 16)) for tl in (1, 2)]   # the two time levels: two allocations
     sph = torch.as_tensor(run.elem["spheremp"].reshape(n, 16), device="cuda:0")
     dp = _dev_tensor(torch, hip.device_ptr("dp")[0], (n, 72, 16))
 
@@ -56,8 +56,9 @@ def test_ne42_q200_full_sphere_properties(monkeypatch):
     chk = (np.sin(9 * run.lon) * np.sin(9 * run.lat) >= 0).astype(np.float64).reshape(n, 16)
     cons = (cm.dss_sum(chk, topo) / cm.dss_sum(np.ones_like(chk), topo) >= 0.5).astype(np.float64)   # single-valued at shared nodes
     hip.dcmip_step_inputs(0, dt); hip.synchronize()
-    Q[:, :, 4:q - 1] = (torch.as_tensor(cons, device="cuda:0")[:, None, :] * dp).unsqueeze(1).unsqueeze(0)
-    Q[:, :, q - 1] = dp.unsqueeze(0)
+    for Qt in Q:
+        Qt[:, 4:q - 1] = (torch.as_tensor(cons, device="cuda:0")[:, None, :] * dp).unsqueeze(1)
+        Qt[:, q - 1] = dp
     torch.cuda.synchronize(); hip.invalidate_cache()
     m0 = mass(1)
     saved0 = Q[0].clone()
@@ -65,9 +66,9 @@ def test_ne42_q200_full_sphere_properties(monkeypatch):
     hip.advec_tracers_remap_rk2(dt, 1, 2); hip.synchronize()
     dvp = _dev_tensor(torch, hip.device_ptr("divdp_proj")[0], (n, 72, 16))
     dp_new = dp - dt * dvp
-    one = Q[1, :, q - 1] / dp_new
+    one = Q[1][:, q - 1] / dp_new
     assert float((one - 1).abs().max()) <= 1e-12, float((one - 1).abs().max())          # consistent advection
-    c01 = Q[1, :, 4:q - 1] / dp_new.unsqueeze(1)
+    c01 = Q[1][:, 4:q - 1] / dp_new.unsqueeze(1)
     assert float(c01.min()) >= -1e-12 and float(c01.max()) <= 1 + 1e-12, (float(c01.min()), float(c01.max()))   # limiter bounds
     del one, c01
     np.testing.assert_allclose(mass(2), m0, rtol=1e-12)

@@ -29,7 +29,7 @@ for i in range(n):
     run.hip.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / 6
     kt = {k: round(run.hip.kernel_time(k)[0] / 6, 2) for k in ("advance0", "advance1", "advance2", "lap", "dss", "minmax", "remap")}
-    ptr = {k: hex(run.hip.device_ptr(k)[0] or 0) for k in ("qdp", "T", "B", "C", "qmin")}
+    ptr = {k: hex(run.hip.device_ptr(k)[0] or 0) for k in ("qdp1", "qdp2", "T", "B", "C", "qmin")}
     print(json.dumps({"ctx": i, "ms_per_step": round(ms, 2), "kernels": kt, "ptr": ptr}), flush=True)
     run.close()
     del run, pad

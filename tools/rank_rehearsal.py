@@ -74,7 +74,7 @@ def main():
                 ptr, _ = h.device_ptr(name)
                 iface = {"shape": shape, "typestr": "<f8", "data": (int(ptr), False), "version": 2}
                 return torch.as_tensor(type("DevArr", (), {"__cuda_array_interface__": iface})(), device="cuda:0")
-            Q = dev("qdp", (2, int(mine.size), a.qsize, 72, 16))
+            Q = [dev("qdp%d" % tl, (int(mine.size), a.qsize, 72, 16)) for tl in (1, 2)]
             res, launches = [], []
             for env in ("1", "0"):
                 os.environ["TSE_DSS_ON_READ"] = env

@@ -59,7 +59,7 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
            "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_precheck", "tse_comm_version", "tse_comm_info", "tse_comm_abort",
-           "tse_boundary_layout", "tse_patch_layout", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass"]
+           "tse_boundary_layout", "tse_patch_layout", "tse_placement", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass"]
 COMM_ID_BYTES = 128
 
 
@@ -115,6 +115,7 @@ def lib():
     L.tse_comm_abort.argtypes = [vp]
     L.tse_boundary_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.tse_patch_layout.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.tse_placement.argtypes = [vp, C.POINTER(i), C.POINTER(d), C.POINTER(i)]
     L.tse_invalidate_cache.argtypes = [vp]
     L.tse_divergence_sphere.argtypes = [vp, vp, vp]
     L.tse_laplace_sphere_wk.argtypes = [vp, vp, vp]

@@ -63,7 +63,12 @@ struct tse_ctx {
   int2 *dss_tab = nullptr, *send_src = nullptr;
   int *nbr = nullptr, *order = nullptr;
   // state
-  double *qdp = nullptr, *T = nullptr, *B = nullptr, *C = nullptr;   // C: third scratch field (stage-3 output of the whole-step path)
+  double *qlev[2] = {nullptr, nullptr};   // Qdp(:,:,:,:,1) and (:,:,:,:,2): two allocations (place_fields)
+  double* q(int tl) const { return qlev[tl - 1]; }
+  double *T = nullptr, *B = nullptr, *C = nullptr;   // C: third scratch field (stage-3 output of the whole-step path)
+  int place_n = 0, place_sel[5] = {0, 1, 2, 3, 4};   // field placement (place_fields): candidates probed, which became T, Qdp1, Qdp2, B, C
+  double place_bw[8] = {0};                          // their streaming-write GB/s, in allocation order
+  std::vector<double*> pool;   // developer experiment (tools/placement_probe.py): scratch-sized allocations T, B, C can be re-assigned to
   double *vn0 = nullptr, *dp = nullptr, *divdp = nullptr, *divdp_proj = nullptr, *eta = nullptr, *omega_p = nullptr;
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
   double *qmin = nullptr, *qmax = nullptr, *qmin2 = nullptr, *qmax2 = nullptr;
@@ -182,6 +187,72 @@ static void gather_strided(std::vector<double>& out, const double* base, size_t 
   out.resize((size_t)n * cnt);
   for (int e = 0; e < n; e++)
     memcpy(&out[(size_t)e * cnt], (const char*)base + (size_t)e * stride_bytes, sizeof(double) * cnt);
+}
+
+// streaming pass over n double2: in -> out (in null: write only; out null: read only); every block works through contiguous 16 KB pieces
+__global__ __launch_bounds__(256) void k_probe_copy(size_t n, const double2* __restrict__ in, double2* __restrict__ out) {
+  const size_t per = 1024;
+  for (size_t p = blockIdx.x; p * per < n; p += gridDim.x)
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const size_t i = p * per + u * 256 + threadIdx.x; if (i < n) { double2 v = in ? in[i] : make_double2(1., 2.); if (out) out[i] = v; else if (v.x == 1.2345e300) ((double2*)in)[i] = v; } }
+}
+
+// Where the five tracer-sized fields live.  The 288 GB are not one uniform memory: streaming WRITES into separately allocated 28 GB
+// chunks run at 5.5 to 6.5 TB/s depending on the chunk (reads: 6.35 everywhere; tools/region_probe.hip), the pattern differs from
+// process to process, is fixed for the life of a process -- and the kernels follow it:
+//  * with the slowest-writing of five chunks as T (written by stages 1 and 3a) a tracer step takes 3 ms longer than with any other
+//    (k_lap1 14.8 instead of 13.4-13.7 ms, k_advance<0,0> 12.6 instead of 12.0; tools/placement_probe.py timed all 60-120 assignments
+//    of three out of five or six chunks with the real kernels);
+//  * k_dss_patch, which writes Qdp(np1), alternates step by step between 16.5 ms and 18.5-19.9 ms: the first half of one 56 GB
+//    allocation for both time levels always writes at 5.5 TB/s, the second at 6.0+ (tools/step_probe.py).
+// Neither can be known beforehand, so tse_init allocates up to TSE_PLACEMENT (default 7, 0 = off) field-sized chunks while memory
+// allows, times a streaming write into each (3 x 5 ms per chunk), gives the five fastest the roles T, Qdp(1), Qdp(2), B, C in that
+// order and frees the rest.  Pure placement: no bit of any result moves.  (profiles/r03_ab_placement.txt)
+static int place_fields(tse_ctx* c, size_t scr_n, size_t trc) {
+  c->place_n = 0;
+  const int want = getenv("TSE_PLACEMENT") ? atoi(getenv("TSE_PLACEMENT")) : 7;
+  const size_t chunk = std::max(scr_n, trc);
+  if (want <= 5 || chunk * 8 < ((size_t)1 << 30)) {   // small fields live in the caches: nothing to choose
+    if (dalloc(&c->qlev[0], trc) || dalloc(&c->qlev[1], trc) || dalloc(&c->T, scr_n) || dalloc(&c->B, scr_n) || dalloc(&c->C, scr_n)) return 1;
+    return 0;
+  }
+  std::vector<double*> cand;
+  const size_t reserve = (size_t)24 << 30;   // what the rest of tse_init allocates (level fields, bounds, halo) and a margin
+  while ((int)cand.size() < std::min(want, 8)) {
+    size_t fr = 0, tot = 0;
+    if (cand.size() >= 5 && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < chunk * 8 + reserve)) break;
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, chunk * 8) != hipSuccess) {
+      (void)hipGetLastError();
+      if (cand.size() >= 5) break;
+      for (double* q : cand) (void)hipFree(q);
+      return 1;
+    }
+    cand.push_back(p);
+  }
+  std::vector<std::pair<double, int>> bw;
+  if (cand.size() > 5) {
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    for (size_t i = 0; i < cand.size(); i++) {
+      hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)cand[i]);
+      HIPCHK(hipEventRecord(a, c->stream));
+      for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)cand[i]);
+      HIPCHK(hipEventRecord(b, c->stream)); HIPCHK(hipEventSynchronize(b));
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+      bw.push_back({(double)chunk * 8 / (ms / 2) / 1e6, (int)i});
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    c->place_n = (int)cand.size();
+    for (size_t i = 0; i < cand.size(); i++) c->place_bw[i] = bw[i].first;
+    std::stable_sort(bw.begin(), bw.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+  } else {
+    for (int i = 0; i < 5; i++) bw.push_back({0.0, i == 0 ? 2 : i <= 2 ? i - 1 : i});   // as before: Qdp1, Qdp2, T, B, C in allocation order
+  }
+  double** role[5] = {&c->T, &c->qlev[0], &c->qlev[1], &c->B, &c->C};
+  for (int r = 0; r < 5; r++) { *role[r] = cand[bw[r].second]; c->place_sel[r] = bw[r].second; }
+  for (size_t i = 5; i < bw.size(); i++) (void)hipFree(cand[bw[i].second]);
+  return 0;
 }
 
 static int init_impl(tse_ctx* c, const tse_init_args* a) {
@@ -579,8 +650,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   c->tps = ((size_t)NCHUNK * c->cse * CL + 15) / 16 * 16;
   if (c->tps < (size_t)n * 16 * NLEV) return fail("tse_init: scratch plane smaller than a tracer plane");
   const size_t scr_n = (size_t)(c->qsize + 1) * c->tps;   // qsize tracer planes + the plane of the stage's extra DSS variable
-  if (dalloc(&c->qdp, 2 * trc) || dalloc(&c->T, scr_n) || dalloc(&c->B, scr_n) || dalloc(&c->C, scr_n))
-    return fail("tse_init: out of device memory (%zu B per tracer field, 5 fields)", trc * 8);
+  if (place_fields(c, scr_n, trc)) return fail("tse_init: out of device memory (%zu B per tracer field, 5 fields)", trc * 8);
   HIPCHK(hipMemset(c->T, 0, scr_n * 8)); HIPCHK(hipMemset(c->B, 0, scr_n * 8)); HIPCHK(hipMemset(c->C, 0, scr_n * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
@@ -588,7 +658,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   // (behind the local elements: room for the received bounds of the compact exchange, see k_unpack_minmax)
   const size_t mm = (size_t)(n + c->nmm_recv) * c->qsize * NLEV;
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
-  HIPCHK(hipMemset(c->qdp, 0, 2 * trc * 8));
+  HIPCHK(hipMemset(c->qlev[0], 0, trc * 8)); HIPCHK(hipMemset(c->qlev[1], 0, trc * 8));
   HIPCHK(hipMemset(c->vn0, 0, 2 * lev * 8)); HIPCHK(hipMemset(c->dp, 0, lev * 8)); HIPCHK(hipMemset(c->divdp, 0, lev * 8));
   HIPCHK(hipMemset(c->divdp_proj, 0, lev * 8)); HIPCHK(hipMemset(c->eta, 0, (size_t)n * NLEVP * 16 * 8));
   HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
@@ -649,10 +719,12 @@ void tse_finalize(tse_ctx* c) {
   for (hipEvent_t e : c->bad_ev) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
-                  c->nbr, c->mm_send_src, c->qdp, c->T, c->B, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
+                  c->nbr, c->mm_send_src, c->qlev[0], c->qlev[1], c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
                   c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (c->pool.empty()) { for (double* p : {c->T, c->B, c->C}) if (p) (void)hipFree(p); }
+  else for (double* p : c->pool) if (p) (void)hipFree(p);
   for (PatchSet& P : c->pset) {
     void* tp[] = {P.pslots, P.plist_bnd, P.plist_int, P.pering, P.pring, P.plds, P.pnb};
     for (void* p : tp) if (p) (void)hipFree(p);
@@ -679,6 +751,14 @@ int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   return 0;
 }
 int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
+// field placement: candidates probed at init (0: none), their streaming-write GB/s in allocation order, and which became
+// T, Qdp(1), Qdp(2), B, C
+int tse_placement(tse_ctx* c, int* ncand, double* write_gbs /* [8] */, int* chosen /* [5] */) {
+  if (ncand) *ncand = c->place_n;
+  if (write_gbs) for (int i = 0; i < 8; i++) write_gbs[i] = i < c->place_n ? c->place_bw[i] : 0.0;
+  if (chosen) for (int r = 0; r < 5; r++) chosen[r] = c->place_sel[r];
+  return 0;
+}
 // patches of the storage tiling that touch another rank (launched first in every stage) and that do not
 int tse_patch_layout(tse_ctx* c, int* np_boundary, int* np_interior) {
   if (np_boundary) *np_boundary = c->pset[0].np_bnd;
@@ -831,14 +911,14 @@ int tse_copy_qdp_h2d(tse_ctx* c, const double* q1, size_t stride, int qsize_d, i
   set_bounds_cache(c, 0);
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_h2d: nt=%d qsize_d=%d", nt, qsize_d);
   const size_t per = (size_t)c->qsize * NLEV * 16;   // Qdp(np,np,nlev,qsize_d,2): time level nt starts qsize_d*nlev*16 doubles in
-  if (copy_field(c, c->qdp + (size_t)(nt - 1) * c->trc(), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, true)) return 1;
+  if (copy_field(c, c->q(nt), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, true)) return 1;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
 int tse_copy_qdp_d2h(tse_ctx* c, double* q1, size_t stride, int qsize_d, int nt) {
   if (nt < 1 || nt > 2 || qsize_d < c->qsize) return fail("tse_copy_qdp_d2h: nt=%d qsize_d=%d", nt, qsize_d);
   const size_t per = (size_t)c->qsize * NLEV * 16;
-  if (copy_field(c, c->qdp + (size_t)(nt - 1) * c->trc(), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, false)) return 1;
+  if (copy_field(c, c->q(nt), per, (char*)q1 + (size_t)(nt - 1) * qsize_d * NLEV * 16 * 8, stride, per, false)) return 1;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -1066,8 +1146,8 @@ static int dss_tracer_pass(tse_ctx* c, const double* src, double* dst, const dou
 static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int DSSopt, int rhs, bool fuse_avg, int avg_n0, bool fused_mm) {
   if (np1_qdp < 1 || np1_qdp > 2 || n0_qdp < 1 || n0_qdp > 2) return fail("euler_step: bad time levels %d %d", np1_qdp, n0_qdp);
   if (rhs < 0 || rhs > 2) return fail("euler_step: rhs_multiplier=%d", rhs);
-  double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
-  double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  double* Qn0 = c->q(n0_qdp);
+  double* Qnp1 = c->q(np1_qdp);
   double** var = DSSopt == 1 ? &c->eta : DSSopt == 2 ? &c->omega_p : DSSopt == 3 ? &c->divdp_proj : nullptr;
   const int var_levels = DSSopt == 1 ? NLEVP : NLEV;
   const int nq = c->qsize * NLEV;
@@ -1113,7 +1193,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
     LAUNCH_CHECK();
   }
   double* pre = rhs == 2 ? c->B : c->T;
-  const double* avg = fuse_avg ? c->qdp + (size_t)(avg_n0 - 1) * c->trc() : nullptr;
+  const double* avg = fuse_avg ? c->q(avg_n0) : nullptr;
   // edgeVpack(Qdp) + edgeVpack(spheremp*DSSvar) -> bndry_exchangeV -> edgeVunpack + rspheremp  (:911-960)
   if (pack_tracers(c, c->stream, pre, nq + NLEV)) return 1;
   if (var && pack_var(c, c->stream, *var, var_levels)) return 1;
@@ -1133,7 +1213,7 @@ int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
   Scope s(c, "avg");
   size_t n = c->trc();
   hipLaunchKernelGGL(k_time_avg, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
-                     c->qdp + (size_t)(n0_qdp - 1) * n, c->qdp + (size_t)(np1_qdp - 1) * n);
+                     c->q(n0_qdp), c->q(np1_qdp));
   LAUNCH_CHECK();
   return 0;
 }
@@ -1189,8 +1269,8 @@ static int split_stage(tse_ctx* c, const char* timer, int kidx /* whose patch ti
 // prefetch: the caller knows that the next thing to happen to Qdp(np1) is the next tracer step (no remap in between), so the
 // bounds exchange that step would start with is started here, under the interior part of the last kernel
 static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp, bool prefetch) {
-  double* Qn0 = c->qdp + (size_t)(n0_qdp - 1) * c->trc();
-  double* Qnp1 = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  double* Qn0 = c->q(n0_qdp);
+  double* Qnp1 = c->q(np1_qdp);
   const int nq = c->qsize * NLEV;
   const dim3 blk(FLAT_THREADS);
   hipStream_t cs = c->comm_stream;
@@ -1329,7 +1409,7 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
   // TSE_REMAP_NT: tracers per thread in the lockstep column loop; TSE_REMAP_GENERIC=1: always take the generic loop (tests)
   const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
   const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
-  double* Qr = c->qdp + (size_t)(np1_qdp - 1) * c->trc();
+  double* Qr = c->q(np1_qdp);
   auto launch = [&](Work w) -> int {   // block = element
     if (!w.nwork) return 0;
     auto go = [&](auto kern, int threads) {
@@ -1410,17 +1490,17 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
   if (dalloc(&d2, lev)) return 1;
   int rc = 0;
   do {
-    if (hipMemcpy(c->qdp, Qdp, c->trc() * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->dp, dp1, lev * 8, hipMemcpyHostToDevice) != hipSuccess ||
+    if (hipMemcpy(c->q(1), Qdp, c->trc() * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->dp, dp1, lev * 8, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d2, dp2, lev * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->divdp_proj, 0, lev * 8) != hipSuccess) { rc = fail("tse_remap_q_ppm: upload failed"); break; }
     const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
     auto go = [&](auto kern) {
       hipLaunchKernelGGL(kern, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->qdp, c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->q(1), c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
                          (const int*)nullptr, c->lvl_tmp);
     };
     if (c->remap_alg2) go(k_remap<1, true>); else go(k_remap<1, false>);
     if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }
-    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(Qdp, c->qdp, c->trc() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("tse_remap_q_ppm: download failed"); break; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(Qdp, c->q(1), c->trc() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail("tse_remap_q_ppm: download failed"); break; }
     rc = remap_check(c);
   } while (0);
   (void)hipFree(d2);
@@ -1434,7 +1514,7 @@ int tse_element_mass(tse_ctx* c, int nt, double* out) {
   const size_t n = (size_t)c->nelemd * c->qsize;
   double* d = nullptr;
   if (dalloc(&d, n)) return 1;
-  hipLaunchKernelGGL(k_elem_mass, dim3((unsigned)n), dim3(128), 0, c->stream, c->qsize, (const double*)(c->qdp + (size_t)(nt - 1) * c->trc()),
+  hipLaunchKernelGGL(k_elem_mass, dim3((unsigned)n), dim3(128), 0, c->stream, c->qsize, (const double*)(c->q(nt)),
                      (const double*)c->spheremp, d);
   int rc = 0;
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1473,7 +1553,7 @@ int tse_dcmip_set_initial(tse_ctx* c) {
   Scope s(c, "dcmip");
   size_t tot = c->lev();
   hipLaunchKernelGGL(k_dcmip_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->dcmip_test, c->lat,
-                     c->lon, c->zm, c->pint, c->dph, c->qdp, c->qdp + c->trc(), c->dp3d, c->ps_v);
+                     c->lon, c->zm, c->pint, c->dph, c->q(1), c->q(2), c->dp3d, c->ps_v);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1535,7 +1615,7 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   struct Ent { const char* n; void* p; size_t b; };
   const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8, scr = (size_t)c->qsize * c->tps * 8;
   const size_t m2 = (size_t)2 * c->qsize * NLEV * 8;
-  Ent ents[] = {{"qdp", c->qdp, 2 * trc}, {"T", c->T, scr + c->tps * 8}, {"B", c->B, scr + c->tps * 8}, {"C", c->C, scr + c->tps * 8}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
+  Ent ents[] = {{"qdp1", c->q(1), trc}, {"qdp2", c->q(2), trc}, {"T", c->T, scr + c->tps * 8}, {"B", c->B, scr + c->tps * 8}, {"C", c->C, scr + c->tps * 8}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
                 {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
                 {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},
                 {"qmax", c->qmax, mm}, {"sendbuf", c->sendbuf, (size_t)c->ncol_send * c->nlyr_halo * 8},
@@ -1544,6 +1624,47 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   for (auto& e : ents) if (!strcmp(e.n, name)) { if (nbytes) *nbytes = e.p ? e.b : 0; return e.p; }
   if (nbytes) *nbytes = 0;
   return nullptr;
+}
+// ---- developer experiment: where the scratch fields live (tools/placement_probe.py) ------------------------------------------
+// make the pool K scratch-sized allocations (the first three are T, B, C as allocated)
+extern "C" int tse_debug_scratch_pool(tse_ctx* c, int K) {
+  const size_t scr_n = (size_t)(c->qsize + 1) * c->tps;
+  if (c->pool.empty()) { c->pool = {c->T, c->B, c->C}; }
+  while ((int)c->pool.size() < K) {
+    double* p = nullptr;
+    if (hipMalloc((void**)&p, scr_n * 8) != hipSuccess) { (void)hipGetLastError(); return fail("tse_debug_scratch_pool: out of memory at %zu chunks", c->pool.size()); }
+    HIPCHK(hipMemset(p, 0, scr_n * 8));
+    c->pool.push_back(p);
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" int tse_debug_zero_pool(tse_ctx* c) {
+  const size_t scr_n = (size_t)(c->qsize + 1) * c->tps;
+  for (double* p : c->pool) HIPCHK(hipMemset(p, 0, scr_n * 8));
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" int tse_debug_assign_scratch(tse_ctx* c, int iT, int iB, int iC) {
+  const int K = (int)c->pool.size();
+  if (iT < 0 || iB < 0 || iC < 0 || iT >= K || iB >= K || iC >= K || iT == iB || iT == iC || iB == iC) return fail("tse_debug_assign_scratch: %d %d %d of %d", iT, iB, iC, K);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  c->T = c->pool[iT]; c->B = c->pool[iB]; c->C = c->pool[iC];
+  return 0;
+}
+// GB/s of a streaming pass: src/dst = -1 none (write-only / read-only), 0..K-1 pool chunk, 100 | 101 = Qdp time level 1 | 2
+extern "C" int tse_debug_probe(tse_ctx* c, int src, int dst, double* gbps) {
+  const size_t n = std::min((size_t)c->qsize * c->tps, c->trc()) / 2;   // double2 units: the smaller of a scratch field and a tracer field
+  auto ptr = [&](int i) -> double2* { return i < 0 ? nullptr : i >= 100 ? (double2*)c->q(i - 99) : (double2*)c->pool[i]; };
+  hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, n, (const double2*)ptr(src), ptr(dst));
+  HIPCHK(hipEventRecord(a, c->stream));
+  for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, n, (const double2*)ptr(src), ptr(dst));
+  HIPCHK(hipEventRecord(b, c->stream)); HIPCHK(hipEventSynchronize(b));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+  *gbps = ((src >= 0) + (dst >= 0)) * (double)n * 16 / (ms / 2) / 1e6;
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return 0;
 }
 int tse_timing(tse_ctx* c, int enable) { resolve_timers(c); c->timing = enable != 0; c->timers.clear(); return 0; }
 int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {

@@ -210,10 +210,10 @@ class PrimRun:
     def state_checksum(self, tl, torch_mod):
         """order-independent checksum of Qdp(:,:,:,:,tl) on this rank: the wrap-around int64 sum of the bit patterns
         (summing it over ranks gives a number that is identical for every partition iff the fields are bit-for-bit equal)"""
-        ptr, nbytes = self.hip.device_ptr("qdp")
+        ptr, nbytes = self.hip.device_ptr("qdp%d" % tl)
         n = self.mine.size * self.qsize * 72 * 16
         self.hip.synchronize()
-        iface = {"shape": (n,), "typestr": "<i8", "data": (int(ptr) + (tl - 1) * n * 8, False), "version": 2}
+        iface = {"shape": (n,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
         holder = type("DevArr", (), {"__cuda_array_interface__": iface})()
         t = torch_mod.as_tensor(holder, device="cuda:%d" % self.hip_device)
         return int(t.sum().item())

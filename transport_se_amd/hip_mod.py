@@ -138,6 +138,13 @@ class HipMod:
         self.L.tse_patch_layout(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def placement(self):
+        """placement of the five tracer-sized fields chosen by tse_init: dict(candidates=n, write_GBs=[...], chosen=[T, Qdp1, Qdp2, B, C]
+        as indices into the candidates); candidates 0 = no choice made"""
+        n = C.c_int(); bw = (C.c_double * 8)(); sel = (C.c_int * 5)()
+        self.L.tse_placement(self.h, C.byref(n), bw, sel)
+        return dict(candidates=n.value, write_GBs=[round(bw[i]) for i in range(n.value)], chosen=[sel[i] for i in range(5)])
+
     def invalidate_cache(self):
         self.L.tse_invalidate_cache(self.h)
 
@@ -283,6 +290,9 @@ class HipMod:
 
     def fetch(self, name, shape):
         """debug/test helper: copy an internal device array to the host (hipMemcpy through torch-free ctypes)"""
+        if name == "qdp":   # the two time levels are two allocations (tse_placement): (2, ...) = [Qdp(..,1), Qdp(..,2)]
+            assert shape[0] == 2, shape
+            return np.stack([self.fetch("qdp1", shape[1:]), self.fetch("qdp2", shape[1:])])
         p, nbytes = self.device_ptr(name)
         out = np.empty(shape, dtype=np.float64)
         assert out.nbytes <= nbytes, (name, out.nbytes, nbytes)
