@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """developer experiment: per-STEP kernel times (the tracer state's two time levels swap roles every step) next to the streaming-write
-rates of the two levels.   python tools/step_probe.py [steps=8]"""
+rates of the two levels.   python tools/step_probe.py [steps=8] [ne=120] [qsize=35]"""
 import ctypes as C
 import json
 import os
@@ -11,7 +11,9 @@ from transport_se_amd.driver import PrimRun  # noqa: E402
 import torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-run = PrimRun(120, 35, test_case=1, device=0, torch_mod=torch)
+ne = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+qs = int(sys.argv[3]) if len(sys.argv) > 3 else 35
+run = PrimRun(ne, qs, test_case=1, device=0, torch_mod=torch)
 L, h = run.hip.L, run.hip.h
 run.hip._chk(L.tse_debug_scratch_pool(h, C.c_int(3)))   # (T, B, C as placed: probe indices 0..2)
 
