@@ -2,7 +2,8 @@
 # registers / LDS / spills of every kernel of the library (hipcc -Rpass-analysis=kernel-resource-usage): tools/kres.sh [pattern] [-DFLAG ...]
 cd "$(dirname "$0")/.."
 pat=${1:-k_}; shift
-hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-honor-nans "$@" -c -o /tmp/kres.o transport_se_amd/csrc/tse_api.hip -Rpass-analysis=kernel-resource-usage 2>&1 | \
+{ hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-honor-nans "$@" -c -o /tmp/kres.o transport_se_amd/csrc/tse_api.hip -Rpass-analysis=kernel-resource-usage 2>&1;
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -fno-honor-nans -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c -o /tmp/kres3.o transport_se_amd/csrc/tse_stage3.hip -Rpass-analysis=kernel-resource-usage 2>&1; } | \
   python3 -c "
 import re,sys
 cur=None; rows={}

@@ -3,7 +3,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from transport_se_amd import _lib
-os.environ["TSE_LIB"] = os.path.join(ROOT, "tools", "libtse_stats.so")
+os.environ["TSE_LIB"] = os.path.join(ROOT, "tools", "ab", "stats.so")   # tools/ab_build.sh stats -DTSE_LIMITER_STATS
 from transport_se_amd.driver import PrimRun
 ne = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 run = PrimRun(ne, 35)

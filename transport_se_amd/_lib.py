@@ -5,7 +5,12 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libtransport_se_hip.so")
-SRC = [os.path.join(HERE, "csrc", f) for f in ("tse_api.hip", "tse_kernels.h", "tse_device.h")]
+SRC = [os.path.join(HERE, "csrc", f) for f in ("tse_api.hip", "tse_stage3.hip", "tse_kernels.h", "tse_device.h")]
+# the translation units and the extra compiler flags of each (tse_stage3.hip says why it has a scheduler strategy of its own)
+UNITS = [("tse_api.hip", []), ("tse_stage3.hip", ["-mllvm", "-amdgpu-sched-strategy=max-ilp"])]
+# -fno-honor-nans: value-preserving (no reassociation, no reciprocal tricks); it only lets the compiler drop the
+# v_max_f64 x,x "canonicalize" it otherwise puts in front of every fmin/fmax operand (6 per limiter iteration)
+CFLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-honor-nans", "-fPIC"]
 HDR = os.path.join(os.path.dirname(HERE), "include", "transport_se_hip.h")
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
@@ -27,19 +32,30 @@ class InitArgs(C.Structure):
     ]
 
 
-def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU)."""
+def build(force=False, verbose=False, out=None, flags=()):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  out/flags: an A/B variant of the same sources (tools/ab_build.sh)"""
     newest = max(os.path.getmtime(p) for p in SRC + [HDR])
-    if not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
+    if out is None and not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
         return SO
-    # -fno-honor-nans: value-preserving (no reassociation, no reciprocal tricks); it only lets the compiler drop the
-    # v_max_f64 x,x "canonicalize" it otherwise puts in front of every fmin/fmax operand (6 per limiter iteration)
-    cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fno-honor-nans", "-shared", "-fPIC", "-o", SO, SRC[0],
-           "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the in-library bndry_exchangeV (tse_comm_init)
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return SO
+    SO_ = out or SO
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        objs, procs = [], []
+        for name, extra in UNITS:   # the two units compile side by side
+            obj = os.path.join(tmp, name.replace(".hip", ".o"))
+            cmd = ["hipcc"] + CFLAGS + extra + list(flags) + ["-c", "-o", obj, os.path.join(HERE, "csrc", name)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd))); objs.append(obj)
+        for cmd, p in procs:
+            if p.wait():
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_] + objs + \
+              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the in-library bndry_exchangeV (tse_comm_init)
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return SO_
 
 
 def source_hash():

@@ -26,6 +26,12 @@
 
 using namespace tse;
 
+namespace tse {   // tse_stage3.hip: k_advance<2,3> lives in a translation unit of its own (another scheduler strategy)
+void launch_advance23(int psz, unsigned blocks, hipStream_t stream, int nelemd, const Dvv_t& D, const GeoPtrs& G, int qsize, double dt, double nu_q,
+                      const double* B, const double* lapT, double* C, const double* vn0, const double* dp, const double* divdp,
+                      const double* divdp_proj, double* qmin, double* qmax, const double* dp0, const GatherArgs& ga);
+}
+
 // TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
 static bool dss_on_read() { const char* e = getenv("TSE_DSS_ON_READ"); return !(e && e[0] == '0'); }
 
@@ -979,7 +985,7 @@ int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
 
 int tse_compute_divdp(tse_ctx* c) {
   Scope s(c, "level");
-  hipLaunchKernelGGL(k_divdp, dim3(flat_blocks(c->nelemd)), dim3(FLAT_THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->vn0, c->divdp, c->divdp_proj);
+  hipLaunchKernelGGL(k_divdp<>, dim3(flat_blocks(c->nelemd)), dim3(FLAT_THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->vn0, c->divdp, c->divdp_proj);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1029,7 +1035,7 @@ static int pack_tracers(tse_ctx* c, hipStream_t st, const double* scratch, int n
   if (!c->ncol_send) return 0;
   unsigned nb;
   if (halo_items((size_t)c->ncol_send * (nq / CL), &nb)) return 1;
-  hipLaunchKernelGGL(k_pack_scratch, dim3(nb), dim3(256), 0, st, c->ncol_send, nq / CL, c->send_src_s, scratch, c->sendbuf, nlyr_halo, c->scr());
+  hipLaunchKernelGGL(k_pack_scratch<>, dim3(nb), dim3(256), 0, st, c->ncol_send, nq / CL, c->send_src_s, scratch, c->sendbuf, nlyr_halo, c->scr());
   LAUNCH_CHECK();
   return 0;
 }
@@ -1039,7 +1045,7 @@ static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_level
   if (!c->ncol_send || !var) return 0;
   unsigned nb;
   if (halo_items((size_t)c->ncol_send * NLEV, &nb)) return 1;
-  hipLaunchKernelGGL(k_pack, dim3(nb), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var, c->spheremp, c->sendbuf, nq + NLEV, nq, var_levels);
+  hipLaunchKernelGGL(k_pack<>, dim3(nb), dim3(256), 0, st, c->ncol_send, NLEV, c->send_src, var, c->spheremp, c->sendbuf, nq + NLEV, nq, var_levels);
   LAUNCH_CHECK();
   return 0;
 }
@@ -1048,7 +1054,7 @@ static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr,
   if (!c->nmm_send) return 0;
   unsigned nb;
   if (halo_items((size_t)c->nmm_send * (m / 2), &nb)) return 1;
-  hipLaunchKernelGGL(k_pack_minmax, dim3(nb), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
+  hipLaunchKernelGGL(k_pack_minmax<>, dim3(nb), dim3(256), 0, st, c->nmm_send, m, c->mm_send_src,
                      qmin ? qmin : (const double*)c->qmin, qmax ? qmax : (const double*)c->qmax, c->sendbuf_mm, 2 * m, 0);
   LAUNCH_CHECK();
   return 0;
@@ -1059,7 +1065,7 @@ static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo,
   const int nq = nlyr ? nlyr : c->qsize * NLEV;   // layers to copy: the tracer planes, or also the extra variable's plane
   unsigned nb;
   if (halo_items((size_t)c->ncol_recv * (nq / CL), &nb)) return 1;
-  hipLaunchKernelGGL(k_unpack_halo, dim3(nb), dim3(256), 0, st, c->ncol_recv, nq / CL, c->recvbuf, nlyr_halo, field, c->scr(), c->halo0());
+  hipLaunchKernelGGL(k_unpack_halo<>, dim3(nb), dim3(256), 0, st, c->ncol_recv, nq / CL, c->recvbuf, nlyr_halo, field, c->scr(), c->halo0());
   LAUNCH_CHECK();
   return 0;
 }
@@ -1070,7 +1076,7 @@ static int unpack_minmax(tse_ctx* c, hipStream_t st) {
   if (!c->nmm_recv) return 0;
   unsigned nb;
   if (halo_items((size_t)c->nmm_recv * (m / 2), &nb)) return 1;
-  hipLaunchKernelGGL(k_unpack_minmax, dim3(nb), dim3(256), 0, st, c->nmm_recv, m, (const double*)c->recvbuf_mm, c->qmin + (size_t)c->nelemd * m,
+  hipLaunchKernelGGL(k_unpack_minmax<>, dim3(nb), dim3(256), 0, st, c->nmm_recv, m, (const double*)c->recvbuf_mm, c->qmin + (size_t)c->nelemd * m,
                      c->qmax + (size_t)c->nelemd * m);
   LAUNCH_CHECK();
   return 0;
@@ -1103,7 +1109,7 @@ static int dss_level_var(tse_ctx* c, double** varp, int var_levels) {
   Scope s(c, "level");
   // out of place into the field's twin buffer (the source must stay intact while neighbours read it), then swap the two
   double** twin = var_levels == NLEV ? &c->lvl_tmp : &c->eta2;
-  hipLaunchKernelGGL(k_dss_lvl, dim3(8 * dss_blocks_per_xcd<LVL_UNITS>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
+  hipLaunchKernelGGL(k_dss_lvl<>, dim3(8 * dss_blocks_per_xcd<LVL_UNITS>(c->nelemd)), dim3(DSS_FLAT_THREADS), 0, c->stream, c->nelemd, c->dss_tab,
                      c->rspheremp, c->spheremp, *varp, var_levels, *twin, var_levels, c->recvbuf, nq + NLEV, nq, c->order);
   LAUNCH_CHECK();
   std::swap(*varp, *twin);
@@ -1159,7 +1165,7 @@ static int euler_step_impl(tse_ctx* c, int np1_qdp, int n0_qdp, double dt, int D
       std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
     } else {
       Scope s(c, "minmax");
-      hipLaunchKernelGGL(k_qminmax, grid, blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
+      hipLaunchKernelGGL(k_qminmax<>, grid, blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
       LAUNCH_CHECK();
     }
     set_bounds_cache(c, 0);
@@ -1212,7 +1218,7 @@ int tse_qdp_time_avg(tse_ctx* c, int rkstage, int n0_qdp, int np1_qdp) {
   set_bounds_cache(c, 0);
   Scope s(c, "avg");
   size_t n = c->trc();
-  hipLaunchKernelGGL(k_time_avg, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
+  hipLaunchKernelGGL(k_time_avg<>, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, c->stream, n, rkstage,
                      c->q(n0_qdp), c->q(np1_qdp));
   LAUNCH_CHECK();
   return 0;
@@ -1288,7 +1294,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
   } else {
     Scope s(c, "minmax");
-    hipLaunchKernelGGL(k_qminmax, dim3(flat_blocks(c->nelemd)), blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
+    hipLaunchKernelGGL(k_qminmax<>, dim3(flat_blocks(c->nelemd)), blk, 0, c->stream, c->nelemd, c->qsize, 0.0, Qn0, c->dp, c->divdp_proj, c->qmin, c->qmax);
     LAUNCH_CHECK();
   }
   set_bounds_cache(c, 0);
@@ -1346,12 +1352,8 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   if (split_stage(c, "advance2", K_ADV2,
         [&](Work w) -> int {
           if (!w.npwork) return 0;
-          with_shape(w.P->psz, [&](auto psz) {
-            constexpr int Z = decltype(psz)::value;
-            hipLaunchKernelGGL((k_advance<2, 3, true, Z>), dim3(patch_blocks(w.npwork)), dim3(Patch<Z>::THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts,
-                               c->nu_q, (const double*)c->B, (const double*)c->T, c->C, c->vn0, c->dp, c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0,
-                               gargs(w, c->omega_p, NLEV));
-            return 0; });
+          launch_advance23(w.P->psz, patch_blocks(w.npwork), c->stream, c->nelemd, c->D, c->geo(), c->qsize, dts, c->nu_q, c->B, c->T, c->C, c->vn0, c->dp,
+                           c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w, c->omega_p, NLEV));   // (tse_stage3.hip)
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->C, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->C, nqv, nqv); })) return 1;
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
@@ -1386,7 +1388,7 @@ static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefe
   if (gor) {
     if (c->t_zero_dirty) {   // restore the all-zero slots of T
       const int tot = c->qsize * NCHUNK * 16 * CL;
-      hipLaunchKernelGGL(k_zero_slot, dim3((tot + 255) / 256), dim3(256), 0, c->stream, c->qsize, c->T, c->scr(), c->zero0());
+      hipLaunchKernelGGL(k_zero_slot<>, dim3((tot + 255) / 256), dim3(256), 0, c->stream, c->qsize, c->T, c->scr(), c->zero0());
       LAUNCH_CHECK();
       c->t_zero_dirty = false;
     }
@@ -1514,7 +1516,7 @@ int tse_element_mass(tse_ctx* c, int nt, double* out) {
   const size_t n = (size_t)c->nelemd * c->qsize;
   double* d = nullptr;
   if (dalloc(&d, n)) return 1;
-  hipLaunchKernelGGL(k_elem_mass, dim3((unsigned)n), dim3(128), 0, c->stream, c->qsize, (const double*)(c->q(nt)),
+  hipLaunchKernelGGL(k_elem_mass<>, dim3((unsigned)n), dim3(128), 0, c->stream, c->qsize, (const double*)(c->q(nt)),
                      (const double*)c->spheremp, d);
   int rc = 0;
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
@@ -1543,7 +1545,7 @@ int tse_dcmip_init(tse_ctx* c, int test, const double* lat, const double* lon, c
   c->lat = c->lon = c->zm = c->zi = c->pint = c->dph = nullptr;
   if (upload(&c->lat, la) || upload(&c->lon, lo) || upload(&c->zm, zm) || upload(&c->zi, zi) || upload(&c->pint, pint) || upload(&c->dph, dph)) return 1;
   if (!c->dcmip_tab && dalloc(&c->dcmip_tab, 1)) return 1;
-  hipLaunchKernelGGL(k_dcmip_tables, dim3(1), dim3(128), 0, c->stream, test, c->zm, c->zi, c->dcmip_tab);   // level-only factors
+  hipLaunchKernelGGL(k_dcmip_tables<>, dim3(1), dim3(128), 0, c->stream, test, c->zm, c->zi, c->dcmip_tab);   // level-only factors
   LAUNCH_CHECK();
   return 0;
 }
@@ -1552,7 +1554,7 @@ int tse_dcmip_set_initial(tse_ctx* c) {
   if (!c->dcmip_test) return fail("tse_dcmip_set_initial: call tse_dcmip_init first");
   Scope s(c, "dcmip");
   size_t tot = c->lev();
-  hipLaunchKernelGGL(k_dcmip_init, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->dcmip_test, c->lat,
+  hipLaunchKernelGGL(k_dcmip_init<>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->qsize, c->dcmip_test, c->lat,
                      c->lon, c->zm, c->pint, c->dph, c->q(1), c->q(2), c->dp3d, c->ps_v);
   LAUNCH_CHECK();
   return 0;
@@ -1564,7 +1566,7 @@ int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
   double t_wind = (nstep > 0 ? nstep - 1 : 0) * tstep, t_now = nstep * tstep;
   // derived%dp is rewritten with the same time-independent p_i(k+1) - p_i(k) on every step (dcmip_wrapper_mod.F90:183,199), so
   // the cached next-step bounds (formed with that dp) stay valid; every other writer of dp drops them (tse_set_derived)
-  hipLaunchKernelGGL(k_dcmip_step, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
+  hipLaunchKernelGGL(k_dcmip_step<>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
                      c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dcmip_static ? nullptr : c->dp, c->eta, c->dcmip_static ? nullptr : c->omega_p);
   LAUNCH_CHECK();
   c->dcmip_static = true;   // until someone else writes dp or omega_p (tse_set_derived, tse_invalidate_cache)

@@ -79,6 +79,7 @@ struct GeoPtrs {
 
 // ---------------------------------------------------------------------------------------------------
 // divdp = divdp_proj = divergence_sphere(vn0)   (prim_advection_mod.F90:614-623)
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ __launch_bounds__(FLAT_THREADS) void k_divdp(int nelemd, Dvv_t D, GeoPtrs G, const double* __restrict__ vn0,
                                                         double* __restrict__ divdp, double* __restrict__ divdp_proj) {
   const SlabId sid = flat_slab(nelemd);
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(256) void k_elem_op(int nelemd, Dvv_t D, GeoPtrs G,
 // diagnostics (global_norms_mod.F90:39-86, prim_state_mod.F90:352-385) -- in a FIXED order (points 0..15 inside a level, then
 // levels 0..71), so that an element's partial does not depend on which rank or block computed it; the cross-element sum is
 // done by the caller with an exact (order-independent) summation.  block = (element, tracer), thread = level.
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ __launch_bounds__(128) void k_elem_mass(int qsize, const double* __restrict__ Q, const double* __restrict__ spheremp, double* __restrict__ out) {
   __shared__ double lev[NLEV];
   const int e = blockIdx.x / qsize, q = blockIdx.x - e * qsize, k = threadIdx.x;
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(128) void k_elem_mass(int qsize, const double* __re
 
 // ---------------------------------------------------------------------------------------------------
 // element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize, double rdt /* rhs_multiplier*dt */,
                                                           const double* __restrict__ Qn0, const double* __restrict__ dp,
                                                           const double* __restrict__ divdp_proj,
@@ -435,6 +438,7 @@ __device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
 // thread = (one chunk of one plane, halo column), columns fastest: a chunk's halo columns are contiguous in the scratch layout
 // (32 bytes each), so the stores are whole lines; the loads are 32-byte pieces of the [col][layer] buffer
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_unpack_halo(int ncol, int ng /* layers / CL: (tracer or extra-variable plane, chunk) pairs */, const double* __restrict__ recvbuf,
                               int nlyr_halo, double* __restrict__ dst, Scr S, unsigned halo0 /* entry index of halo column 0 within a chunk */) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,6 +452,7 @@ __global__ void k_unpack_halo(int ncol, int ng /* layers / CL: (tracer or extra-
 }
 // received element bounds (compact min/max exchange: [col][min set | max set]) -> behind the local elements of qmin / qmax, where the
 // stage-3 kernel's element ring finds them (entry nelemd + col)
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_unpack_minmax(int ncol, int m /* even */, const double* __restrict__ recvbuf, double* __restrict__ qmin_tail, double* __restrict__ qmax_tail) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, h = (unsigned)m / 2;
   if (t >= (unsigned)ncol * h) return;
@@ -457,6 +462,7 @@ __global__ void k_unpack_minmax(int ncol, int m /* even */, const double* __rest
   *reinterpret_cast<double2*>(qmax_tail + (size_t)col * m + l) = *reinterpret_cast<const double2*>(in + m);
 }
 // the all-zero slot of every chunk of every plane (after a caller used the scratch field as a plain buffer)
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned zero0 /* entry index of the zero slot */) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= qsize * NCHUNK * 16 * CL) return;
@@ -918,6 +924,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
 // element (eta_dot_dpdn: nlev+1; the extra level is copied through), so no staging copies are needed and the caller just
 // swaps the two buffers.  Lanes flattened over (element slot, level pair, row); all gathers issued before any use.
 constexpr int LVL_UNITS = (NLEV / 2) * 4;   // lanes per element: 36 level pairs (k, k+36) x 4 rows
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const int2* __restrict__ tab, const double* __restrict__ rspheremp,
                                                               const double* __restrict__ spheremp, const double* __restrict__ src, int src_lev,
                                                               double* __restrict__ dst, int dst_lev, const double* __restrict__ recvbuf,
@@ -980,6 +987,7 @@ __global__ __launch_bounds__(DSS_FLAT_THREADS) void k_dss_lvl(int nelemd, const 
 
 // pack the rank-boundary columns of a [e][nlyr][16] field into sendbuf[col][nlyr_halo] (layer fastest, the
 // reference's buf(nlyr,nbuf) layout, edge_mod.F90:150,177-196); send_src[col] = {element, point}
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, const double* __restrict__ src,
                        const double* __restrict__ scale_in, double* __restrict__ sendbuf, int nlyr_halo, int lyr0,
                        int src_lyr /* layers per element of src (>= nlyr; eta_dot_dpdn carries nlev+1) */) {
@@ -993,6 +1001,7 @@ __global__ void k_pack(int ncol, int nlyr, const int2* __restrict__ send_src, co
 }
 // the same from a scratch field (send_src_s[col] = {slot, position}): thread = (column, chunk of a plane) moves the chunk's
 // 4 levels -- 32 contiguous bytes on both sides -- layers fastest, so the stores are whole lines
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_pack_scratch(int ncol, int ng /* layers / CL */, const int2* __restrict__ send_src_s, const double* __restrict__ src,
                                double* __restrict__ sendbuf, int nlyr_halo, Scr S) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1005,6 +1014,7 @@ __global__ void k_pack_scratch(int ncol, int ng /* layers / CL */, const int2* _
   *reinterpret_cast<double2*>(out) = a; *reinterpret_cast<double2*>(out + 2) = b;
 }
 // element-constant min/max fields packed the way neighbor_minmax does (viscosity_mod.F90:764-774); two entries per thread
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_pack_minmax(int ncol, int m /* even */, const int2* __restrict__ send_src, const double* __restrict__ qmin,
                               const double* __restrict__ qmax, double* __restrict__ sendbuf, int nlyr_halo, int lyr0) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x, h = (unsigned)m / 2;
@@ -1017,6 +1027,7 @@ __global__ void k_pack_minmax(int ncol, int m /* even */, const int2* __restrict
 }
 
 // qdp_time_avg alone (prim_advection_mod.F90:645-662), for the stage-by-stage API
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_time_avg(size_t n, int rkstage, const double* __restrict__ Qn0, double* __restrict__ Qnp1) {
   size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
   if (t >= n) return;
@@ -1637,6 +1648,7 @@ __device__ inline DcmipPt dcmip_point(int test, double time, double lon, double 
 // allows it, so the values are identical), k_dcmip_step evaluates the column-only factors once per column and step and
 // then only multiplies.
 struct DcmipTab { double m1[NLEV], m2[NLEV], i1[NLEVP], i2[NLEVP], i3[NLEVP]; };
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_dcmip_tables(int test, const double* __restrict__ zm, const double* __restrict__ zi, DcmipTab* __restrict__ T) {
   const int k = threadIdx.x;
   if (k >= NLEVP) return;
@@ -1672,6 +1684,7 @@ __global__ void k_dcmip_tables(int test, const double* __restrict__ zm, const do
     }
   }
 }
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ __launch_bounds__(256) void k_dcmip_step(int nelemd, int test, double t_wind, double t_now, const double* __restrict__ lat,
                                                     const double* __restrict__ lon, const DcmipTab* __restrict__ T,
                                                     const double* __restrict__ pint, double* __restrict__ vn0, double* __restrict__ dp,
@@ -1721,6 +1734,7 @@ __global__ __launch_bounds__(256) void k_dcmip_step(int nelemd, int test, double
 
 // initial tracers: Qdp(:,:,:,q,1:2) = Q*dp(hyai,hybi,ps_v=p0) (prim_driver_mod.F90:646-669); checkerboard for the extra
 // tracers (dcmip_wrapper_mod.F90:215-243)
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
 __global__ void k_dcmip_init(int nelemd, int qsize, int test, const double* __restrict__ lat, const double* __restrict__ lon,
                              const double* __restrict__ zm, const double* __restrict__ pint, const double* __restrict__ dph,
                              double* __restrict__ qdp0, double* __restrict__ qdp1, double* __restrict__ dp3d,
