@@ -298,8 +298,8 @@ def main():
                          "traffic_ratio_vs_pipeline": traffic_step / pipe_bytes_step if traffic_step else None},
             "l2_dcmip11": l2_record(a.ne),
             "rccl": rccl,
-            # which of the scratch-sized chunks probed at init became T, B, C (device memory is not uniform for writes: DESIGN.md section 6)
-            "placement": run.hip.placement(),
+            # the chunks tried at init for T, Qdp1, Qdp2, B, C, their streaming-write rates and which try each field kept
+            "placement": (lambda p: dict(p, write_GBs=[round(x) for x in p["write_GBs"]]))(run.hip.placement()),
             "kernel_ms_per_step": {k: v[0] / a.steps for k, v in ktimes.items()},
             "kernel_source_hash": kernel_source_hash(),
             # wrap-around int64 sum of the bit patterns of the final Qdp over all ranks: equal for every --gpus N

@@ -196,10 +196,12 @@ void *tse_device_ptr(tse_ctx *ctx, const char *name, size_t *nbytes);
  * "advance" (= "advance0" + "advance1" + "advance2", the three RK stages), "dss", "lap", "minmax", "remap", "level", "dcmip", "avg" */
 int tse_kernel_time(tse_ctx *ctx, const char *name, double *ms, long *launches);
 int tse_timing(tse_ctx *ctx, int enable); /* enable/disable + reset per-kernel event timing */
-/* where the five tracer-sized fields were placed (tse_init times a streaming write into up to TSE_PLACEMENT, default 7, field-sized
- * chunks and keeps the five fastest: device memory is not uniform for writes): number of candidates probed (0: no
- * choice was made), their write rates in GB/s in allocation order, and the indices of the five that became T, Qdp(1), Qdp(2), B, C */
-int tse_placement(tse_ctx *ctx, int *ncand, double *write_gbs /* [8] */, int *chosen /* [5] */);
+/* where the five tracer-sized fields were placed (device memory is not uniform for writes and the rate is a property of the
+ * allocation: tse_init tries field-sized chunks -- up to TSE_PLACEMENT, default 20, in all, up to 8 held at a time, the slowest given
+ * back and the next one allocated behind a small pad -- until three of them take a streaming write at TSE_PLACEMENT_GOOD, default
+ * 6000 GB/s, and keeps the five fastest): number of chunks tried (0: no choice was made), their write rates in
+ * GB/s in the order tried, and which try became T, Qdp(1), Qdp(2), B, C */
+int tse_placement(tse_ctx *ctx, int *ntried, double *write_gbs /* [32] */, int *chosen /* [5] */);
 int tse_halo_layout(tse_ctx *ctx, int *ncol_send, int *ncol_recv);
 /* per-slot entry counts of the kind-1 (min/max) exchange, in send-slot / recv-slot order */
 int tse_halo_minmax_layout(tse_ctx *ctx, int *send_len, int *recv_len);

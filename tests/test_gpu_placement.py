@@ -1,6 +1,6 @@
-"""-m gpu: field placement (tse_init times a streaming write into up to TSE_PLACEMENT field-sized chunks and gives the five fastest
-the roles T, Qdp(1), Qdp(2), B, C).  Pure placement: the state after the same steps is the same bits with and
-without it, the report names distinct chunks, and T is the fastest-writing one."""
+"""-m gpu: field placement (tse_init tries field-sized chunks until three of those it holds take a streaming write at
+TSE_PLACEMENT_GOOD, and gives the five fastest the roles T, Qdp(1), Qdp(2), B, C).  Pure placement: the state after
+the same steps is the same bits with and without it, and the report is consistent with the rule."""
 import numpy as np
 import pytest
 
@@ -25,14 +25,15 @@ def _run(monkeypatch, placement):
 
 def test_placement_moves_no_bit_and_reports_its_choice(monkeypatch):
     off, q0 = _run(monkeypatch, "0")
-    assert off["candidates"] == 0
+    assert off["tried"] == 0
     on, q1 = _run(monkeypatch, None)
-    assert on["candidates"] == 7 and len(set(on["chosen"])) == 5 and all(0 <= i < 7 for i in on["chosen"])
-    bw = on["write_GBs"]
-    assert all(1000 < b < 9000 for b in bw), bw
-    ranked = [bw[i] for i in on["chosen"]]
-    assert ranked == sorted(ranked, reverse=True) and ranked[0] == max(bw) and ranked[-1] >= sorted(bw)[2]
+    bw, sel = on["write_GBs"], on["chosen"]
+    assert 5 <= on["tried"] <= 20 and len(bw) == on["tried"] and len(set(sel)) == 5 and all(1000 < b < 9000 for b in bw), on
+    ranked = [bw[i] for i in sel]
+    assert ranked == sorted(ranked, reverse=True), on                  # T gets the fastest, then Qdp(1), Qdp(2), B, C
+    assert on["tried"] == 20 or ranked[2] >= 6000, on                  # it stopped early only with three good chunks in hand
     assert np.array_equal(q0.view(np.uint64), q1.view(np.uint64))
-    six, q2 = _run(monkeypatch, "6")
-    assert six["candidates"] == 6
+    monkeypatch.setenv("TSE_PLACEMENT_GOOD", "1e9")    # never good enough: the whole budget is used
+    nine, q2 = _run(monkeypatch, "9")
+    assert nine["tried"] == 9
     assert np.array_equal(q0.view(np.uint64), q2.view(np.uint64))

@@ -1,6 +1,6 @@
 // tools/region_probe.hip -- developer tool: is every region of the 288 GB equally fast?  Allocates N chunks of G GiB, and times a streaming
 // read, a streaming write and an in-place read-modify-write of each chunk, then a copy between every pair of the first four.
-//   hipcc -O3 --offload-arch=gfx950 -o region_probe region_probe.hip ;  ./region_probe [N=9] [G=28]
+//   hipcc -O3 --offload-arch=gfx950 -o region_probe region_probe.hip ;  ./region_probe [N=9] [G=28] [S: map of S-GiB pieces instead of the pair copies; -P: re-roll test with pads of P MiB]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +29,27 @@ __global__ __launch_bounds__(256) void k_copy(size_t n, const double2* __restric
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 9;
   const size_t bytes = (size_t)(argc > 2 ? atoi(argv[2]) : 28) << 30, n = bytes / 16;
+  if (argc > 3 && atoi(argv[3]) < 0) {   // re-roll: does the same memory behind a small pad write at another rate?
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    auto t = [&](auto launch) { launch(); CK(hipDeviceSynchronize()); CK(hipEventRecord(a)); launch(); launch(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / 2; };
+    const size_t pad = (size_t)(-atoi(argv[3])) << 20;
+    std::vector<char*> held;
+    for (int k = 0; k < N; k++) {   // k held chunks in front (never freed), then a fresh one probed 3 times with a pad allocated between the tries
+      printf("with %d chunk(s) held:", k);
+      std::vector<char*> pads;
+      for (int r = 0; r < 4; r++) {
+        char* p; CK(hipMalloc(&p, bytes));
+        const float w = t([&] { hipLaunchKernelGGL(k_write, dim3(2048), dim3(256), 0, 0, n, (double2*)p); });
+        printf("  %p %4.0f", (void*)p, bytes / w / 1e6);
+        if (r == 3) { held.push_back(p); break; }
+        CK(hipFree(p));
+        char* q; CK(hipMalloc(&q, pad)); pads.push_back(q);
+      }
+      for (char* q : pads) CK(hipFree(q));
+      printf("\n");
+    }
+    return 0;
+  }
   std::vector<char*> buf(N);
   double* out; CK(hipMalloc(&out, 4096));
   for (int i = 0; i < N; i++) { CK(hipMalloc(&buf[i], bytes)); CK(hipMemset(buf[i], 0, bytes)); }
@@ -41,6 +62,39 @@ int main(int argc, char** argv) {
     const float w = t([&] { hipLaunchKernelGGL(k_write, g, blk, 0, 0, n, (double2*)buf[i]); });
     const float u = t([&] { hipLaunchKernelGGL(k_copy, g, blk, 0, 0, n, (const double2*)buf[i], (double2*)buf[i]); });
     printf("chunk %d at %p: read %6.0f GB/s  write %6.0f GB/s  update in place %6.0f GB/s (r+w)\n", i, (void*)buf[i], bytes / r / 1e6, bytes / w / 1e6, 2.0 * bytes / u / 1e6);
+  }
+  if (argc > 3) {   // map: the write rate of every S-GiB piece of every chunk, then of 1-GiB allocations of their own
+    const size_t sub = (size_t)atoi(argv[3]) << 30;
+    for (int i = 0; i < N; i++) {
+      printf("chunk %d write GB/s per %d GiB:", i, atoi(argv[3]));
+      for (size_t o = 0; o + sub <= bytes; o += sub) {
+        const float w = t([&] { hipLaunchKernelGGL(k_write, g, blk, 0, 0, sub / 16, (double2*)(buf[i] + o)); });
+        printf(" %4.0f", sub / w / 1e6);
+      }
+      printf("\n");
+    }
+    for (int i = 0; i < N; i++) {   // how long must a write be for a slow chunk to show?
+      printf("chunk %d write GB/s over its first 1, 2, 4, 8, 16, all GiB:", i);
+      for (size_t len = (size_t)1 << 30; ; len *= 2) {
+        const size_t l = len < bytes ? len : bytes;
+        const float w = t([&] { hipLaunchKernelGGL(k_write, g, blk, 0, 0, l / 16, (double2*)buf[i]); });
+        printf(" %4.0f", l / w / 1e6);
+        if (l == bytes) break;
+      }
+      printf("   last 8 GiB: ");
+      { const size_t l = (size_t)8 << 30; const float w = t([&] { hipLaunchKernelGGL(k_write, g, blk, 0, 0, l / 16, (double2*)(buf[i] + bytes - l)); }); printf("%4.0f", l / w / 1e6); }
+      printf("\n");
+    }
+    for (int i = 0; i < N; i++) CK(hipFree(buf[i]));
+    std::vector<char*> small;
+    for (int i = 0; i < (argc > 4 ? 250 : 0); i++) { char* p; if (hipMalloc(&p, (size_t)1 << 30) != hipSuccess) break; small.push_back(p); }
+    printf("%zu allocations of 1 GiB, write GB/s of each:\n", small.size());
+    for (size_t i = 0; i < small.size(); i++) {
+      const float w = t([&] { hipLaunchKernelGGL(k_write, g, blk, 0, 0, ((size_t)1 << 30) / 16, (double2*)small[i]); });
+      printf(" %4.0f%s", ((size_t)1 << 30) / w / 1e6, i % 25 == 24 ? "\n" : "");
+    }
+    printf("\n");
+    return 0;
   }
   const int M = N < 5 ? N : 5;
   for (int i = 0; i < M; i++) {

@@ -72,8 +72,9 @@ struct tse_ctx {
   double *qlev[2] = {nullptr, nullptr};   // Qdp(:,:,:,:,1) and (:,:,:,:,2): two allocations (place_fields)
   double* q(int tl) const { return qlev[tl - 1]; }
   double *T = nullptr, *B = nullptr, *C = nullptr;   // C: third scratch field (stage-3 output of the whole-step path)
-  int place_n = 0, place_sel[5] = {0, 1, 2, 3, 4};   // field placement (place_fields): candidates probed, which became T, Qdp1, Qdp2, B, C
-  double place_bw[8] = {0};                          // their streaming-write GB/s, in allocation order
+  int place_n = 0, place_sel[5] = {0, 1, 2, 3, 4};   // field placement (place_fields): chunks tried, which try became T, Qdp1, Qdp2, B, C
+  double place_bw[32] = {0};                         // their streaming-write GB/s, in the order tried
+  double* qorig[2] = {nullptr, nullptr};   // developer experiment: the tracer state's own allocations while it lives in pool chunks
   std::vector<double*> pool;   // developer experiment (tools/placement_probe.py): scratch-sized allocations T, B, C can be re-assigned to
   double *vn0 = nullptr, *dp = nullptr, *divdp = nullptr, *divdp_proj = nullptr, *eta = nullptr, *omega_p = nullptr;
   double *dp3d = nullptr, *ps_v = nullptr, *lvl_tmp = nullptr;
@@ -94,6 +95,11 @@ struct tse_ctx {
   // in-library exchange: RCCL communicator + communication stream; elements that touch another rank / that do not
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
+  // the prescribed-wind generator of step n+1 runs beside the neighbour min/max pass that opens the step (tse_prim_run_subcycle): its own
+  // stream, forked behind the last launch of step n, joined before the first kernel that reads vn0 / eta_dot_dpdn
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_inputs = nullptr;
+  bool inputs_pending = false;
   std::vector<hipEvent_t> sync_events; size_t sync_next = 0;
   int *ord_bnd = nullptr, *ord_int = nullptr;
   int n_bnd = 0, n_int = 0;
@@ -162,12 +168,12 @@ static hipEvent_t get_event(tse_ctx* c) {
   hipEvent_t e = nullptr; (void)hipEventCreate(&e); return e;
 }
 struct Scope {
-  tse_ctx* c; const char* name; hipEvent_t a = nullptr;
-  Scope(tse_ctx* c_, const char* n) : c(c_), name(n) { if (c->timing) { a = get_event(c); (void)hipEventRecord(a, c->stream); } }
+  tse_ctx* c; const char* name; hipEvent_t a = nullptr; hipStream_t st;
+  Scope(tse_ctx* c_, const char* n, hipStream_t st_ = nullptr) : c(c_), name(n), st(st_ ? st_ : c_->stream) { if (c->timing) { a = get_event(c); (void)hipEventRecord(a, st); } }
   ~Scope() {
     if (!a) return;
     hipEvent_t b = get_event(c);
-    (void)hipEventRecord(b, c->stream);
+    (void)hipEventRecord(b, st);
     c->pending.push_back({name, a, b});
   }
 };
@@ -204,61 +210,71 @@ __global__ __launch_bounds__(256) void k_probe_copy(size_t n, const double2* __r
 }
 
 // Where the five tracer-sized fields live.  The 288 GB are not one uniform memory: streaming WRITES into separately allocated 28 GB
-// chunks run at 5.5 to 6.5 TB/s depending on the chunk (reads: 6.35 everywhere; tools/region_probe.hip), the pattern differs from
-// process to process, is fixed for the life of a process -- and the kernels follow it:
-//  * with the slowest-writing of five chunks as T (written by stages 1 and 3a) a tracer step takes 3 ms longer than with any other
-//    (k_lap1 14.8 instead of 13.4-13.7 ms, k_advance<0,0> 12.6 instead of 12.0; tools/placement_probe.py timed all 60-120 assignments
-//    of three out of five or six chunks with the real kernels);
-//  * k_dss_patch, which writes Qdp(np1), alternates step by step between 16.5 ms and 18.5-19.9 ms: the first half of one 56 GB
-//    allocation for both time levels always writes at 5.5 TB/s, the second at 6.0+ (tools/step_probe.py).
-// Neither can be known beforehand, so tse_init allocates up to TSE_PLACEMENT (default 7, 0 = off) field-sized chunks while memory
-// allows, times a streaming write into each (3 x 5 ms per chunk), gives the five fastest the roles T, Qdp(1), Qdp(2), B, C in that
-// order and frees the rest.  Pure placement: no bit of any result moves.  (profiles/r03_ab_placement.txt)
+// chunks run at 5.5 to 6.9 TB/s depending on the chunk (reads: 6.35 everywhere; tools/region_probe.hip); the rate is a property of the
+// allocation (of how its physical memory happens to be put together: the same virtual range freed and allocated again behind a small
+// pad writes at another rate; in short bursts all chunks are alike), it is fixed for the life of the allocation -- and the kernels
+// follow it:
+//  * with a 5.5 TB/s chunk as T (written by stages 1 and 3a) a tracer step takes 2-3 ms longer than with any faster one (k_lap1 14.8
+//    instead of 13.4-13.7 ms, k_advance<0,0> 12.6 instead of 12.0; tools/placement_probe.py timed all 60-120 assignments of three out
+//    of five or six chunks with the real kernels);
+//  * k_dss_patch, which writes Qdp(np1), takes 16.3-17.1 ms into a chunk that streams at 5.9 TB/s or more and 18.5-19.3 ms into one
+//    at 5.5-5.7 (tools/dss_probe.py); with both time levels in one allocation it alternated between the two step by step, the
+//    first allocation of a process being a slow one nearly always (tools/step_probe.py).
+// This was the unexplained "run-to-run modes" of rounds 1 and 2.  So tse_init places the five fields by trial: it allocates field-sized
+// chunks (up to 8 held at a time, memory allowing) and times a streaming write into each (3 x 5 ms); as long as fewer than three of the
+// held chunks reach TSE_PLACEMENT_GOOD (6000 GB/s) it frees the slowest, allocates a 256 MB pad and tries again -- at most
+// TSE_PLACEMENT tries in all (default 20; 0 = off).  The five fastest become T, Qdp(1), Qdp(2), B, C in that order (the first three are
+// the roles that matter), the rest and the pads are freed before anything else is allocated.  Pure placement: no bit of any result moves.
+// (profiles/r03_ab_placement.txt)
 static int place_fields(tse_ctx* c, size_t scr_n, size_t trc) {
   c->place_n = 0;
-  const int want = getenv("TSE_PLACEMENT") ? atoi(getenv("TSE_PLACEMENT")) : 7;
+  const int budget = getenv("TSE_PLACEMENT") ? atoi(getenv("TSE_PLACEMENT")) : 20;
+  const double good = getenv("TSE_PLACEMENT_GOOD") ? atof(getenv("TSE_PLACEMENT_GOOD")) : 6000.0;
   const size_t chunk = std::max(scr_n, trc);
-  if (want <= 5 || chunk * 8 < ((size_t)1 << 30)) {   // small fields live in the caches: nothing to choose
+  double** role[5] = {&c->T, &c->qlev[0], &c->qlev[1], &c->B, &c->C};
+  if (budget <= 5 || chunk * 8 < ((size_t)1 << 30)) {   // small fields live in the caches: nothing to choose
     if (dalloc(&c->qlev[0], trc) || dalloc(&c->qlev[1], trc) || dalloc(&c->T, scr_n) || dalloc(&c->B, scr_n) || dalloc(&c->C, scr_n)) return 1;
     return 0;
   }
-  std::vector<double*> cand;
+  hipEvent_t a, b;
+  HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+  struct Held { double gbs; double* p; int tryno; };
+  std::vector<Held> held;
+  std::vector<void*> pads;
   const size_t reserve = (size_t)24 << 30;   // what the rest of tse_init allocates (level fields, bounds, halo) and a margin
-  while ((int)cand.size() < std::min(want, 8)) {
+  auto ngood = [&]() { int n = 0; for (const Held& h : held) n += h.gbs >= good; return n; };
+  int rc = 0;
+  while (c->place_n < budget) {
+    if (held.size() >= 5 && ngood() >= 3) break;
     size_t fr = 0, tot = 0;
-    if (cand.size() >= 5 && (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < chunk * 8 + reserve)) break;
+    const bool room = held.size() < 5 || (held.size() < 8 && hipMemGetInfo(&fr, &tot) == hipSuccess && fr >= chunk * 8 + reserve);
+    if (!room) {   // give the slowest one back and shift what the next allocation gets
+      size_t w = 0;
+      for (size_t i = 1; i < held.size(); i++) if (held[i].gbs < held[w].gbs) w = i;
+      (void)hipFree(held[w].p); held.erase(held.begin() + w);
+      void* pad = nullptr;
+      if (hipMalloc(&pad, (size_t)256 << 20) == hipSuccess) pads.push_back(pad); else (void)hipGetLastError();
+    }
     double* p = nullptr;
-    if (hipMalloc((void**)&p, chunk * 8) != hipSuccess) {
-      (void)hipGetLastError();
-      if (cand.size() >= 5) break;
-      for (double* q : cand) (void)hipFree(q);
-      return 1;
-    }
-    cand.push_back(p);
+    if (hipMalloc((void**)&p, chunk * 8) != hipSuccess) { (void)hipGetLastError(); if (held.size() < 5) rc = 1; break; }
+    hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)p);
+    (void)hipEventRecord(a, c->stream);
+    for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)p);
+    float ms = 0;
+    if (hipEventRecord(b, c->stream) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipFree(p); rc = 1; break; }
+    const double gbs = (double)chunk * 8 / (ms / 2) / 1e6;
+    if (c->place_n < 32) c->place_bw[c->place_n] = gbs;
+    held.push_back({gbs, p, c->place_n++});
   }
-  std::vector<std::pair<double, int>> bw;
-  if (cand.size() > 5) {
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    for (size_t i = 0; i < cand.size(); i++) {
-      hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)cand[i]);
-      HIPCHK(hipEventRecord(a, c->stream));
-      for (int r = 0; r < 2; r++) hipLaunchKernelGGL(k_probe_copy, dim3(2048), dim3(256), 0, c->stream, chunk / 2, (const double2*)nullptr, (double2*)cand[i]);
-      HIPCHK(hipEventRecord(b, c->stream)); HIPCHK(hipEventSynchronize(b));
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
-      bw.push_back({(double)chunk * 8 / (ms / 2) / 1e6, (int)i});
-    }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    c->place_n = (int)cand.size();
-    for (size_t i = 0; i < cand.size(); i++) c->place_bw[i] = bw[i].first;
-    std::stable_sort(bw.begin(), bw.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
-  } else {
-    for (int i = 0; i < 5; i++) bw.push_back({0.0, i == 0 ? 2 : i <= 2 ? i - 1 : i});   // as before: Qdp1, Qdp2, T, B, C in allocation order
+  if (held.size() < 5) rc = 1;
+  std::stable_sort(held.begin(), held.end(), [](const Held& x, const Held& y) { return x.gbs > y.gbs; });
+  for (size_t i = 0; i < held.size(); i++) {
+    if (!rc && i < 5) { *role[i] = held[i].p; c->place_sel[i] = held[i].tryno; }
+    else (void)hipFree(held[i].p);
   }
-  double** role[5] = {&c->T, &c->qlev[0], &c->qlev[1], &c->B, &c->C};
-  for (int r = 0; r < 5; r++) { *role[r] = cand[bw[r].second]; c->place_sel[r] = bw[r].second; }
-  for (size_t i = 5; i < bw.size(); i++) (void)hipFree(cand[bw[i].second]);
-  return 0;
+  for (void* p : pads) (void)hipFree(p);
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  return rc;
 }
 
 static int init_impl(tse_ctx* c, const tse_init_args* a) {
@@ -280,6 +296,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   memcpy(c->D.d, a->Dvv, sizeof c->D.d);
   { std::vector<double> dv(a->Dvv, a->Dvv + 16); if (upload(&c->dvv_d, dv)) return 1; }
   HIPCHK(hipStreamCreate(&c->stream));   // blocking w.r.t. the legacy default stream: see the note above split_stage
+  HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_inputs, hipEventDisableTiming));
   const int n = a->nelemd;
   std::vector<double> h;
   gather_strided(h, a->Dinv, a->Dinv_stride, n, 64);
@@ -725,7 +743,7 @@ void tse_finalize(tse_ctx* c) {
   for (hipEvent_t e : c->bad_ev) if (e) (void)hipEventDestroy(e);
   for (int i = 0; i < 2; i++) { if (c->stage[i]) (void)hipHostFree(c->stage[i]); if (c->stage_ev[i]) (void)hipEventDestroy(c->stage_ev[i]); }
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
-                  c->nbr, c->mm_send_src, c->qlev[0], c->qlev[1], c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
+                  c->nbr, c->mm_send_src, c->qorig[0] ? c->qorig[0] : c->qlev[0], c->qorig[0] ? c->qorig[1] : c->qlev[1], c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
                   c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -740,6 +758,9 @@ void tse_finalize(tse_ctx* c) {
   for (hipEvent_t e : c->sync_events) if (e) (void)hipEventDestroy(e);
   if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -757,11 +778,11 @@ int tse_halo_minmax_layout(tse_ctx* c, int* send_len, int* recv_len) {
   return 0;
 }
 int tse_boundary_layout(tse_ctx* c, int* nb, int* ni) { if (nb) *nb = c->n_bnd; if (ni) *ni = c->n_int; return 0; }
-// field placement: candidates probed at init (0: none), their streaming-write GB/s in allocation order, and which became
-// T, Qdp(1), Qdp(2), B, C
-int tse_placement(tse_ctx* c, int* ncand, double* write_gbs /* [8] */, int* chosen /* [5] */) {
-  if (ncand) *ncand = c->place_n;
-  if (write_gbs) for (int i = 0; i < 8; i++) write_gbs[i] = i < c->place_n ? c->place_bw[i] : 0.0;
+// field placement: chunks tried at init (0: no choice was made), their streaming-write GB/s in the order tried (the first 32), and
+// which try became T, Qdp(1), Qdp(2), B, C
+int tse_placement(tse_ctx* c, int* ntried, double* write_gbs /* [32] */, int* chosen /* [5] */) {
+  if (ntried) *ntried = std::min(c->place_n, 32);
+  if (write_gbs) for (int i = 0; i < 32; i++) write_gbs[i] = i < c->place_n ? c->place_bw[i] : 0.0;
   if (chosen) for (int r = 0; r < 5; r++) chosen[r] = c->place_sel[r];
   return 0;
 }
@@ -1274,6 +1295,13 @@ static int split_stage(tse_ctx* c, const char* timer, int kidx /* whose patch ti
 
 // prefetch: the caller knows that the next thing to happen to Qdp(np1) is the next tracer step (no remap in between), so the
 // bounds exchange that step would start with is started here, under the interior part of the last kernel
+// the step's inputs (vn0, eta_dot_dpdn; dp, omega_p on the first step) are being written on the auxiliary stream: wait for them
+static int join_inputs(tse_ctx* c) {
+  if (!c->inputs_pending) return 0;
+  HIPCHK(hipStreamWaitEvent(c->stream, c->ev_inputs, 0));
+  c->inputs_pending = false;
+  return 0;
+}
 static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp, bool prefetch) {
   double* Qn0 = c->q(n0_qdp);
   double* Qnp1 = c->q(np1_qdp);
@@ -1289,6 +1317,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
 
   // ---- stage 1 (rhs_multiplier 0, DSS extra = divdp_proj): bounds, neighbour min/max, advance Qdp(n0) -> T
   const bool halo_ready = c->halo() && c->mm_valid == n0_qdp && c->mm_halo == n0_qdp;   // prefetched by the previous step / remap
+  if (c->mm_valid != n0_qdp && join_inputs(c)) return 1;   // k_qminmax reads dp
   if (c->mm_valid == n0_qdp) {
     // the previous step's last kernel (final DSS or remap) already left the element min/max of Qdp(n0)/dp in qmin2/qmax2
     std::swap(c->qmin, c->qmin2); std::swap(c->qmax, c->qmax2);
@@ -1310,6 +1339,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
   }
   if (nbr_minmax_kernel(c)) return 1;
+  if (join_inputs(c)) return 1;   // (the wind generator ran beside the neighbour min/max pass)
   if (split_stage(c, "advance0", K_ADV1,
         [&](Work w) -> int {
           if (!w.nwork) return 0;
@@ -1375,6 +1405,7 @@ static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefe
   if (n0_qdp == np1_qdp || n0_qdp < 1 || n0_qdp > 2 || np1_qdp < 1 || np1_qdp > 2)
     return fail("advec_tracers_remap_rk2: time levels n0_qdp=%d np1_qdp=%d", n0_qdp, np1_qdp);
   bool gor = dss_on_read();
+  if (!gor && join_inputs(c)) return 1;
   // gather offsets are 32-bit bytes within a plane; TSE_TEST_PLANE_LIMIT lowers the 4 GiB limit so that tests reach the fallback
   const size_t plane_limit = getenv("TSE_TEST_PLANE_LIMIT") ? (size_t)strtoull(getenv("TSE_TEST_PLANE_LIMIT"), nullptr, 10) : ((size_t)1 << 32);
   if (gor && c->tps * 8 >= plane_limit) {
@@ -1384,6 +1415,7 @@ static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefe
       said = true;
     }
     gor = false;
+    if (join_inputs(c)) return 1;
   }
   if (gor) {
     if (c->t_zero_dirty) {   // restore the all-zero slots of T
@@ -1559,19 +1591,20 @@ int tse_dcmip_set_initial(tse_ctx* c) {
   LAUNCH_CHECK();
   return 0;
 }
-int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) {
+static int dcmip_step_launch(tse_ctx* c, int nstep, double tstep, hipStream_t st) {
   if (!c->dcmip_test) return fail("tse_dcmip_step_inputs: call tse_dcmip_init first");
-  Scope s(c, "dcmip");
+  Scope s(c, "dcmip", st);
   size_t tot = (size_t)c->nelemd * 16;   // one thread per column
   double t_wind = (nstep > 0 ? nstep - 1 : 0) * tstep, t_now = nstep * tstep;
   // derived%dp is rewritten with the same time-independent p_i(k+1) - p_i(k) on every step (dcmip_wrapper_mod.F90:183,199), so
   // the cached next-step bounds (formed with that dp) stay valid; every other writer of dp drops them (tse_set_derived)
-  hipLaunchKernelGGL(k_dcmip_step<>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nelemd, c->dcmip_test, t_wind, t_now,
+  hipLaunchKernelGGL(k_dcmip_step<>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, c->nelemd, c->dcmip_test, t_wind, t_now,
                      c->lat, c->lon, c->dcmip_tab, c->pint, c->vn0, c->dcmip_static ? nullptr : c->dp, c->eta, c->dcmip_static ? nullptr : c->omega_p);
   LAUNCH_CHECK();
   c->dcmip_static = true;   // until someone else writes dp or omega_p (tse_set_derived, tse_invalidate_cache)
   return 0;
 }
+int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) { return join_inputs(c) || dcmip_step_launch(c, nstep, tstep, c->stream); }
 int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
   const int nstep0 = *nstep_io;
   int nstep = nstep0;
@@ -1588,6 +1621,7 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
     fail("negative layer thickness.  timestep or remap time too large");
     return 2;
   };
+  const bool overlap_inputs = !(getenv("TSE_INPUT_OVERLAP") && getenv("TSE_INPUT_OVERLAP")[0] == '0');
   for (int s = 0; s < nsub; s++) {
     if (s >= 2) {
       HIPCHK(hipEventSynchronize(c->bad_ev[s & 1]));
@@ -1595,7 +1629,13 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
     }
     int n0 = 1, np1 = 2;
     for (int r = 0; r < c->rsplit; r++) {
-      if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
+      if (overlap_inputs) {   // fork: behind everything launched so far (the previous step / remap read what this writes)
+        HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+        if (dcmip_step_launch(c, nstep, tstep, c->aux_stream)) return 1;
+        HIPCHK(hipEventRecord(c->ev_inputs, c->aux_stream));
+        c->inputs_pending = true;   // joined by the step before its first kernel that reads them (join_inputs)
+      } else if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
       if (nstep % 2 == 0) { n0 = 1; np1 = 2; } else { n0 = 2; np1 = 1; }  // TimeLevel_Qdp, time_mod.F90:85-109
       if (advec_step(c, tstep, n0, np1, r + 1 < c->rsplit)) return 1;   // (the remap follows the last one: its bounds would be stale)
       nstep++;
@@ -1652,6 +1692,17 @@ extern "C" int tse_debug_assign_scratch(tse_ctx* c, int iT, int iB, int iC) {
   if (iT < 0 || iB < 0 || iC < 0 || iT >= K || iB >= K || iC >= K || iT == iB || iT == iC || iB == iC) return fail("tse_debug_assign_scratch: %d %d %d of %d", iT, iB, iC, K);
   HIPCHK(hipStreamSynchronize(c->stream));
   c->T = c->pool[iT]; c->B = c->pool[iB]; c->C = c->pool[iC];
+  return 0;
+}
+// the tracer state's two time levels in pool chunks i1, i2 (the state must be set again afterwards)
+extern "C" int tse_debug_assign_qdp(tse_ctx* c, int i1, int i2) {
+  const int K = (int)c->pool.size();
+  if (i1 < 0 || i2 < 0 || i1 >= K || i2 >= K || i1 == i2) return fail("tse_debug_assign_qdp: %d %d of %d", i1, i2, K);
+  for (double* p : {c->T, c->B, c->C}) if (p == c->pool[i1] || p == c->pool[i2]) return fail("tse_debug_assign_qdp: chunk in use as scratch");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  if (!c->qorig[0]) { c->qorig[0] = c->qlev[0]; c->qorig[1] = c->qlev[1]; }
+  c->qlev[0] = c->pool[i1]; c->qlev[1] = c->pool[i2];
+  c->mm_valid = 0;
   return 0;
 }
 // GB/s of a streaming pass: src/dst = -1 none (write-only / read-only), 0..K-1 pool chunk, 100 | 101 = Qdp time level 1 | 2

@@ -139,11 +139,11 @@ class HipMod:
         return a.value, b.value
 
     def placement(self):
-        """placement of the five tracer-sized fields chosen by tse_init: dict(candidates=n, write_GBs=[...], chosen=[T, Qdp1, Qdp2, B, C]
-        as indices into the candidates); candidates 0 = no choice made"""
-        n = C.c_int(); bw = (C.c_double * 8)(); sel = (C.c_int * 5)()
+        """placement of the five tracer-sized fields by tse_init: dict(tried=n, write_GBs=[... in the order tried], chosen=[T, Qdp1, Qdp2, B, C]
+        as indices into the tries); tried 0 = no choice made"""
+        n = C.c_int(); bw = (C.c_double * 32)(); sel = (C.c_int * 5)()
         self.L.tse_placement(self.h, C.byref(n), bw, sel)
-        return dict(candidates=n.value, write_GBs=[round(bw[i]) for i in range(n.value)], chosen=[sel[i] for i in range(5)])
+        return dict(tried=n.value, write_GBs=[bw[i] for i in range(n.value)], chosen=[sel[i] for i in range(5)])
 
     def invalidate_cache(self):
         self.L.tse_invalidate_cache(self.h)
