@@ -37,3 +37,20 @@ def test_placement_moves_no_bit_and_reports_its_choice(monkeypatch):
     nine, q2 = _run(monkeypatch, "9")
     assert nine["tried"] == 9
     assert np.array_equal(q0.view(np.uint64), q2.view(np.uint64))
+
+
+def test_placement_under_memory_pressure_gives_chunks_back_instead_of_holding_eight(monkeypatch):
+    """with room for little more than the five fields themselves the trial keeps five chunks and re-allocates the slowest"""
+    import torch
+    off, q0 = _run(monkeypatch, "0")
+    free, total = torch.cuda.mem_get_info(0)
+    chunk = 36 * 5400 * 16 * 72 * 8                      # a scratch field of ne30/q35: qsize + 1 planes
+    hog = torch.empty(free - (24 << 30) - 6 * chunk, dtype=torch.uint8, device="cuda:0")   # leaves 24 GiB (the reserve) + 6 chunks
+    try:
+        monkeypatch.setenv("TSE_PLACEMENT_GOOD", "1e9")
+        on, q1 = _run(monkeypatch, "12")
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert on["tried"] == 12 and len(set(on["chosen"])) == 5, on
+    assert np.array_equal(q0.view(np.uint64), q1.view(np.uint64))
