@@ -138,6 +138,7 @@ struct tse_ctx {
     return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, P.pslots, P.pring, P.plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, nullptr,
                       P.pering, P.pnb, pperm};
   }
+  int mm_m() const { return mm_qpad(qsize) * NLEV; }   // entries per element of the bounds arrays (tse_kernels.h: mm_idx)
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
   size_t trc() const { return lev() * qsize; }
   DcmipTab* dcmip_tab = nullptr;   // level-only factors of the prescribed fields
@@ -678,15 +679,16 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   HIPCHK(hipMemset(c->T, 0, scr_n * 8)); HIPCHK(hipMemset(c->B, 0, scr_n * 8)); HIPCHK(hipMemset(c->C, 0, scr_n * 8));
   if (dalloc(&c->vn0, 2 * lev) || dalloc(&c->dp, lev) || dalloc(&c->divdp, lev) || dalloc(&c->divdp_proj, lev) ||
       dalloc(&c->eta, (size_t)n * NLEVP * 16) || dalloc(&c->omega_p, lev) || dalloc(&c->dp3d, lev) || dalloc(&c->ps_v, (size_t)n * 16) ||
-      dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)NLEV * c->qsize) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
+      dalloc(&c->lvl_tmp, lev) || dalloc(&c->sink, (size_t)NLEV * 16 + 2 * (size_t)c->mm_m()) || dalloc(&c->eta2, (size_t)n * NLEVP * 16)) return 1;
   // (behind the local elements: room for the received bounds of the compact exchange, see k_unpack_minmax)
-  const size_t mm = (size_t)(n + c->nmm_recv) * c->qsize * NLEV;
+  const size_t mm = (size_t)(n + c->nmm_recv) * c->mm_m();
   if (dalloc(&c->qmin, mm) || dalloc(&c->qmax, mm) || dalloc(&c->qmin2, mm) || dalloc(&c->qmax2, mm) || dalloc(&c->bad, 1)) return 1;
   HIPCHK(hipMemset(c->qlev[0], 0, trc * 8)); HIPCHK(hipMemset(c->qlev[1], 0, trc * 8));
   HIPCHK(hipMemset(c->vn0, 0, 2 * lev * 8)); HIPCHK(hipMemset(c->dp, 0, lev * 8)); HIPCHK(hipMemset(c->divdp, 0, lev * 8));
   HIPCHK(hipMemset(c->divdp_proj, 0, lev * 8)); HIPCHK(hipMemset(c->eta, 0, (size_t)n * NLEVP * 16 * 8));
   HIPCHK(hipMemset(c->omega_p, 0, lev * 8)); HIPCHK(hipMemset(c->dp3d, 0, lev * 8)); HIPCHK(hipMemset(c->ps_v, 0, (size_t)n * 16 * 8));
   HIPCHK(hipMemset(c->qmin, 0, mm * 8)); HIPCHK(hipMemset(c->qmax, 0, mm * 8));
+  HIPCHK(hipMemset(c->qmin2, 0, mm * 8)); HIPCHK(hipMemset(c->qmax2, 0, mm * 8));   // (the pad tracers of the layout are exchanged and reduced like the others)
   HIPCHK(hipMemset(c->bad, 0, sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&c->bad_host, 2 * sizeof(int), hipHostMallocDefault));
   c->bad_host[0] = c->bad_host[1] = 0;
@@ -696,7 +698,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   // (element, direction) pair) have their own buffers, so that the two exchanges of stage 3 can be in flight together.
   c->nlyr_halo = c->qsize * NLEV + NLEV;
   if (c->halo()) {
-    const size_t m2 = (size_t)2 * c->qsize * NLEV;
+    const size_t m2 = (size_t)2 * c->mm_m();
     if (dalloc(&c->sendbuf, (size_t)std::max(1, c->ncol_send) * c->nlyr_halo) || dalloc(&c->recvbuf, (size_t)std::max(1, c->ncol_recv) * c->nlyr_halo) ||
         dalloc(&c->sendbuf_mm, (size_t)std::max(1, c->nmm_send) * m2) || dalloc(&c->recvbuf_mm, (size_t)std::max(1, c->nmm_recv) * m2)) return 1;
     int lo = 0, hi = 0;
@@ -985,7 +987,7 @@ int tse_get_derived(tse_ctx* c, double* divdp_proj, size_t s1, double* eta, size
   return 0;
 }
 int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
-  const size_t mm = (size_t)c->nelemd * c->qsize * NLEV;
+  const size_t mm = (size_t)c->nelemd * c->mm_m();
   HIPCHK(hipStreamSynchronize(c->stream));
   std::vector<double> h(mm);
   double* outs[2] = {qmin, qmax};
@@ -996,7 +998,7 @@ int tse_get_qminmax(tse_ctx* c, double* qmin, double* qmax) {
     for (int e = 0; e < c->nelemd; e++)          // device layout [e][k / CL][q][k % CL] (tse_kernels.h: mm_idx) -> [e][q][k]
       for (int q = 0; q < c->qsize; q++)
         for (int k = 0; k < NLEV; k++)
-          outs[a][((size_t)e * c->qsize + q) * NLEV + k] = h[(((size_t)e * NCHUNK + k / CL) * c->qsize + q) * CL + (k % CL)];
+          outs[a][((size_t)e * c->qsize + q) * NLEV + k] = h[(((size_t)e * NCHUNK + k / CL) * mm_qpad(c->qsize) + q) * CL + (k % CL)];
   }
   return 0;
 }
@@ -1071,7 +1073,7 @@ static int pack_var(tse_ctx* c, hipStream_t st, const double* var, int var_level
   return 0;
 }
 static int pack_minmax(tse_ctx* c, hipStream_t st, const double* qmin = nullptr, const double* qmax = nullptr) {
-  const int m = c->qsize * NLEV;
+  const int m = c->mm_m();
   if (!c->nmm_send) return 0;
   unsigned nb;
   if (halo_items((size_t)c->nmm_send * (m / 2), &nb)) return 1;
@@ -1093,7 +1095,7 @@ static int unpack_halo(tse_ctx* c, hipStream_t st, double* field, int nlyr_halo,
 
 // received element bounds -> behind the local elements of qmin/qmax (read by the stage-3 kernel through its element ring)
 static int unpack_minmax(tse_ctx* c, hipStream_t st) {
-  const int m = c->qsize * NLEV;
+  const int m = c->mm_m();
   if (!c->nmm_recv) return 0;
   unsigned nb;
   if (halo_items((size_t)c->nmm_recv * (m / 2), &nb)) return 1;
@@ -1105,7 +1107,7 @@ static int unpack_minmax(tse_ctx* c, hipStream_t st) {
 
 // min/max over the <= 8 neighbours of qmin/qmax (double-buffered on the device); the halo part must have arrived
 static int nbr_minmax_kernel(tse_ctx* c) {
-  const int m = c->qsize * NLEV;
+  const int m = c->mm_m();
   {
     Scope s(c, "minmax");
     hipLaunchKernelGGL(k_nbr_minmax_patch<8>, dim3(nbr_patch_blocks(c->pset[0].npatch, c->qsize)), dim3(512), 0, c->stream, c->pset[0].npatch, c->qsize, c->nbr,
@@ -1118,7 +1120,7 @@ static int nbr_minmax_kernel(tse_ctx* c) {
 // neighbor_minmax (viscosity_mod.F90:748-816), everything on the compute stream (per-stage API)
 static int neighbor_minmax(tse_ctx* c) {
   if (pack_minmax(c, c->stream)) return 1;
-  if (halo_exchange(c, 2 * c->qsize * NLEV, 1, c->stream)) return 1;
+  if (halo_exchange(c, 2 * c->mm_m(), 1, c->stream)) return 1;
   return nbr_minmax_kernel(c);
 }
 
@@ -1334,7 +1336,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     hipEvent_t ev0 = next_sync_event(c), evM = next_sync_event(c);
     HIPCHK(hipEventRecord(ev0, c->stream));
     HIPCHK(hipStreamWaitEvent(cs, ev0, 0));
-    if (pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs)) return 1;
+    if (pack_minmax(c, cs) || halo_exchange(c, 2 * c->mm_m(), 1, cs)) return 1;
     HIPCHK(hipEventRecord(evM, cs));
     HIPCHK(hipStreamWaitEvent(c->stream, evM, 0));
   }
@@ -1375,7 +1377,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
                                (const double*)c->B, c->T, c->dp, c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
             return 0; });
           LAUNCH_CHECK(); return 0; },
-        [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * nq, 1, cs) || unpack_minmax(c, cs) || pack_tracers(c, cs, c->T, nq) ||
+        [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * c->mm_m(), 1, cs) || unpack_minmax(c, cs) || pack_tracers(c, cs, c->T, nq) ||
                               halo_exchange(c, nq, 0, cs) || unpack_halo(c, cs, c->T, nq); })) return 1;
   // (no neighbour min/max pass here: 3b forms it from the element bounds -- its patch's and the element ring's -- while it runs)
   // 3b: B (+) edges, T (+) edges -> C (2nd Laplacian + biharmonic scaling + advance + limiter)
@@ -1391,7 +1393,7 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
     hipEvent_t done = nullptr;
     if (split_stage(c, "dss", K_DSS,
           [&](Work w) -> int { return dss_tracer_launch(c, c->C, Qnp1, Qn0, w.plist, w.npwork, c->omega_p, NLEV); },
-          [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done)) return 1;
+          [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * c->mm_m(), 1, cs); }, &done)) return 1;
     set_bounds_cache(c, np1_qdp);
     c->mm_halo = np1_qdp;
   } else {
@@ -1463,7 +1465,7 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
     const int nq = c->qsize * NLEV;
     hipStream_t cs = c->comm_stream;
     hipEvent_t done = nullptr;
-    if (split_stage(c, "remap", K_DSS, launch, [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * nq, 1, cs); }, &done))
+    if (split_stage(c, "remap", K_DSS, launch, [&]() -> int { return pack_minmax(c, cs, c->qmin2, c->qmax2) || halo_exchange(c, 2 * c->mm_m(), 1, cs); }, &done))
       return 1;
     set_bounds_cache(c, np1_qdp);   // k_remap emitted the element min/max of the remapped field
     c->mm_halo = np1_qdp;
@@ -1655,8 +1657,8 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
 // ---- introspection ------------------------------------------------------------------------------
 void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   struct Ent { const char* n; void* p; size_t b; };
-  const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->qsize * NLEV * 8, scr = (size_t)c->qsize * c->tps * 8;
-  const size_t m2 = (size_t)2 * c->qsize * NLEV * 8;
+  const size_t lev = c->lev() * 8, trc = c->trc() * 8, mm = (size_t)c->nelemd * c->mm_m() * 8, scr = (size_t)c->qsize * c->tps * 8;
+  const size_t m2 = (size_t)2 * c->mm_m() * 8;
   Ent ents[] = {{"qdp1", c->q(1), trc}, {"qdp2", c->q(2), trc}, {"T", c->T, scr + c->tps * 8}, {"B", c->B, scr + c->tps * 8}, {"C", c->C, scr + c->tps * 8}, {"vn0", c->vn0, 2 * lev}, {"dp", c->dp, lev},
                 {"divdp", c->divdp, lev}, {"divdp_proj", c->divdp_proj, lev}, {"eta_dot_dpdn", c->eta, (size_t)c->nelemd * NLEVP * 16 * 8},
                 {"omega_p", c->omega_p, lev}, {"dp3d", c->dp3d, lev}, {"ps_v", c->ps_v, (size_t)c->nelemd * 16 * 8}, {"qmin", c->qmin, mm},

@@ -9,7 +9,7 @@
 //                  (points / halo columns) per chunk.  A plane is < 4 GB, so the DSS-on-read kernels address it with one
 //                  uniform base + 32-bit byte offsets.
 //   level fields   dp, divdp, divdp_proj, omega_p, dp3d [e][k][p]; vn0[e][k][c][p]; eta_dot_dpdn[e][73][p]
-//   bounds         qmin/qmax[e][kc][q][kk] (mm_idx): the 4 levels of a chunk fastest, then the tracer, so that the 32 bytes a
+//   bounds         qmin/qmax[e][kc][q (rounded up to a multiple of 4)][kk] (mm_idx): the 4 levels of a chunk fastest, then the tracer, so that the 32 bytes a
 //                  (patch x chunk) block needs per element and tracer share their line with the next three tracers
 //   metric         Dinv[e][p][4], metdet/rmetdet/spheremp/rspheremp[e][p]
 // Every slab kernel uses the row-per-lane layout of tse_device.h: thread = (slab (e,k), row j), looping over the tracers so
@@ -54,7 +54,10 @@ struct Scr { size_t tps; unsigned cse; };   // plane stride (doubles), entries p
 // two that three of the four edges straddled with one fixed perimeter-first order.
 __host__ __device__ __forceinline__ int ppos(unsigned long long perm, int p) { return (int)((perm >> (4 * p)) & 15ull); }
 // qmin/qmax(k,q,e) of prim_advection_mod (:459) in the device layout [e][k / CL][q][k % CL]
-__device__ __forceinline__ size_t mm_idx(int e, int q, int k, int qsize) { return (((size_t)e * NCHUNK + k / CL) * qsize + q) * CL + (k % CL); }
+// (the tracer count of the bounds layout is rounded up to a multiple of 4: the 4 levels of 4 consecutive tracers are one aligned
+// 128-byte line, so that the kernels that emit bounds can write whole lines)
+__host__ __device__ __forceinline__ int mm_qpad(int qsize) { return (qsize + 3) & ~3; }
+__device__ __forceinline__ size_t mm_idx(int e, int q, int k, int qsize) { return (((size_t)e * NCHUNK + k / CL) * mm_qpad(qsize) + q) * CL + (k % CL); }
 // Blocks are dealt round-robin to the 8 XCDs, so logical block = (blockIdx % 8) * (gridDim/8) + blockIdx / 8 gives every
 // XCD a contiguous range of slabs (and the ranges coincide with the element ranges the DSS kernels walk per XCD).
 struct SlabId { int e, k; bool live; };
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(FLAT_THREADS) void k_qminmax(int nelemd, int qsize,
 // structure is wave-uniform (scalar loads and branches).  8 GB per launch at ne120/q35: 1.9 ms; one element per block with all
 // 8 neighbours from global memory (L2) took 2.45 ms, 16 waves with one slot each 2.15, 4 waves with four slots 2.0.
 constexpr int MM_TILE = 64;
-inline int nbr_patch_blocks(int npatch, int qsize) { return 8 * ((npatch + 7) / 8) * ((qsize * NLEV / 2 + MM_TILE - 1) / MM_TILE); }
+inline int nbr_patch_blocks(int npatch, int qsize) { return 8 * ((npatch + 7) / 8) * ((mm_qpad(qsize) * NLEV / 2 + MM_TILE - 1) / MM_TILE); }
 template <int WB /* waves per block; a wave serves PS / WB element slots */>
 __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qsize, const int* __restrict__ nbr, const int* __restrict__ pslots,
                                                              const int* __restrict__ slot_of, const double* __restrict__ in_min,
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qs
                                                              double* __restrict__ out_max, const double* __restrict__ recvbuf, int nlyr_halo) {
   __shared__ double2 smn[PS][MM_TILE], smx[PS][MM_TILE];
   constexpr int R = PS / WB;
-  const int m = qsize * NLEV;
+  const int m = mm_qpad(qsize) * NLEV;   // entries per element of the bounds layout
   // the 8 XCDs each take a contiguous range of patches and walk it tile by tile: the patches whose elements a block reads
   // from global memory ran the same tile on the same XCD a few blocks earlier
   const int npx = (npatch + 7) >> 3, x = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -385,6 +388,35 @@ __device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds<PSZ>
 }
 // all LDS writes of the workgroup have landed; the loads of the next tracer stay in flight (no vmcnt wait)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+
+// Element bounds out of a patch kernel: staged in LDS over 4 consecutive tracers and written as whole 128-byte lines (the layout keeps
+// the 4 levels of 4 consecutive tracers of an (element, chunk) in one aligned line: mm_idx).  One 8-byte store per (element, level,
+// tracer) -- what these kernels did before -- leaves every line to be filled by four tracers at four different times, and the memory
+// system pays for a partial line as for a whole one and more: 1.6 ms of k_lap1's 12.8 and 1.65 of k_dss_patch's 16.8 for 6 % of their
+// bytes (profiles/r03_ab_bounds_lines.txt).
+template <int PSZ> struct BoundsStage { double v[2][2][PSZ][4][CL]; };   // [group parity][min|max][slot][tracer & 3][level]: 8 KB (4x4 patch)
+template <int PSZ>
+__device__ __forceinline__ void stage_init(BoundsStage<PSZ>& S) {   // (the pad tracers of the last group are written too: defined values)
+  double2* p = reinterpret_cast<double2*>(&S.v[0][0][0][0][0]);
+  p[threadIdx.x] = make_double2(0., 0.); p[threadIdx.x + PSZ * 16] = make_double2(0., 0.);   // PSZ*16 lanes x 2 x 16 B = 2*2*PSZ*16*8
+}
+template <int PSZ>
+__device__ __forceinline__ void stage_bounds(BoundsStage<PSZ>& S, int q, double mn, double mx) {   // lane = (slot, level, row): rows 0 and 1 write
+  const int t = threadIdx.x, sl = t >> 4, kk = (t >> 2) & (CL - 1), j = t & 3;
+  if (j == 0) S.v[(q >> 2) & 1][0][sl][q & 3][kk] = mn;
+  if (j == 1) S.v[(q >> 2) & 1][1][sl][q & 3][kk] = mx;
+}
+// the two lines per slot of tracers 4g .. 4g+3: one 16-byte store per lane; call behind a workgroup barrier that follows their stage_bounds
+template <int PSZ>
+__device__ __forceinline__ void flush_bounds(const BoundsStage<PSZ>& S, int g, const int* __restrict__ pslots, int patch, int kchunk, int qsize,
+                                             double* __restrict__ mn_out, double* __restrict__ mx_out) {
+  const int t = threadIdx.x, a = t / (PSZ * 8), sl = (t >> 3) % PSZ, piece = t & 7;
+  const int el = pslots[patch * PSZ + sl];
+  if (el < 0) return;   // hole
+  const double2 v = *reinterpret_cast<const double2*>(&S.v[g & 1][a][sl][piece >> 1][(piece & 1) * 2]);
+  double* dst = (a ? mx_out : mn_out) + (((size_t)el * NCHUNK + kchunk) * mm_qpad(qsize) + g * 4) * CL + piece * 2;
+  *reinterpret_cast<double2*>(dst) = v;
+}
 // the reference's order per point: edge contributions (S, E, N, W) first, then the corner; an absent one adds +0.0
 template <int PSZ>
 __device__ __forceinline__ void gather_sum(const RowGather& R, const PatchLds<PSZ>& L, int b, int j, const double v[4], double out[4]) {
@@ -573,7 +605,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     const int t = threadIdx.x, u = min(t >> 2, BND_ENT - 1), w = (t >> 1) & 1, h = t & 1;   // lanes beyond the image repeat its last entry
     int el = u < PSZ ? GA.pslots[pid.patch * PSZ + u] : GA.pering[pid.patch * NER + (u - PSZ)];
     if (el < 0) el = pid.e;   // hole
-    bsrc = (unsigned)((((size_t)el * NCHUNK + kc / CL) * qsize) * CL + h * 2);   // + q*CL: entry index in qmin / qmax (< 2^32: the arrays are < 32 GB)
+    bsrc = (unsigned)((((size_t)el * NCHUNK + kc / CL) * mm_qpad(qsize)) * CL + h * 2);   // + q*CL: entry index in qmin / qmax (< 2^32: the arrays are < 32 GB)
     bbase = w ? qmax : qmin;
     bdst = (unsigned)(((u * 2 + w) * CL + h * 2) * 8);
     // the 9 entries of a slab (its element, then the 8 neighbours) are shared out over the quad: row j takes entries j, j+4 (and 8)
@@ -734,6 +766,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
                                                        const double* __restrict__ dp, const double* __restrict__ divdp_proj,
                                                        double* __restrict__ qmin, double* __restrict__ qmax, GatherArgs GA) {
   __shared__ PatchLds<PSZ> lds_;
+  __shared__ BoundsStage<PSZ> stg_;   // (GIN only)
   int e, k, kc, slot;
   const int j = threadIdx.x & 3;
   PatchId pid{};
@@ -793,8 +826,8 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
   struct Out { double l[4], mn, mx; };
   auto put = [&](const Out& o, int q) {   // stores of tracer q
     store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.l);
-    if (k < NLEV && j == 0) { qmin[mm_idx(e, q, k, qsize)] = o.mn; qmax[mm_idx(e, q, k, qsize)] = o.mx; }
   };
+  stage_init(stg_);   // (ordered before its first use by the first tracer's barrier)
   auto step = [&](int q, const Out* prev, Out& cur) {
     double x[4], own[4];
     gather_publish(RG, lds_, q & 1, kc, graw, own);
@@ -803,11 +836,13 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
     gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, graw);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    if ((q & 3) == 0 && q) flush_bounds(stg_, (q >> 2) - 1, GA.pslots, pid.patch, kc / CL, qsize, qmin, qmax);   // the element bounds of the 4 tracers before
     gather_sum(RG, lds_, q & 1, j, own, x);
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
     cur.mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     cur.mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
+    stage_bounds(stg_, q, cur.mn, cur.mx);
     laplace_lean_row(D, L, x, cur.l);
   };
   Out A, B;
@@ -816,6 +851,8 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
   for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
   if (q < qsize) { step(q, &A, B); put(B, q); }
   else put(A, q - 1);
+  lds_barrier();
+  flush_bounds(stg_, (qsize - 1) >> 2, GA.pslots, pid.patch, kc / CL, qsize, qmin, qmax);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -856,6 +893,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
                                                             const double* __restrict__ Qn0, const double* __restrict__ dpnext,
                                                             double* __restrict__ mn_out, double* __restrict__ mx_out, GatherArgs GA) {
   __shared__ PatchLds<PSZ> lds_;
+  __shared__ BoundsStage<PSZ> stg_;   // (MODE 1 with mn_out only)
   const PatchId pid = patch_slab<PSZ>(GA);
   if (!pid.any) return;   // whole block (uniform): before any barrier
   const int e = pid.e, kc = pid.k, k = pid.live ? pid.k : NLEV, j = pid.j;
@@ -876,9 +914,10 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
   auto put = [&](const Out& o, int q) {
     if (k < NLEV) {
       store4(dst + (((size_t)e * qsize + q) * NLEV + k) * 16 + j * 4, o.x);
-      if (MODE == 1 && mn_out && j == 0) { const size_t mi = mm_idx(e, q, k, qsize); mn_out[mi] = o.mn; mx_out[mi] = o.mx; }
     }
   };
+  const bool emit = MODE == 1 && mn_out;   // (kernel argument: uniform)
+  if (emit) stage_init(stg_);
   // wait for this tracer's loads -> publish in LDS -> issue the PREVIOUS tracer's stores and the NEXT tracer's loads ->
   // workgroup barrier -> neighbour values from LDS -> sum (results alternate between two register sets, see k_lap1)
   auto step = [&](int q, const Out* prev, Out& cur) {
@@ -894,15 +933,17 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
     fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    if (emit && (q & 3) == 0 && q) flush_bounds(stg_, (q >> 2) - 1, GA.pslots, pid.patch, kc / CL, qsize, mn_out, mx_out);   // the bounds of the 4 tracers before
     gather_sum(RG, lds_, q & 1, j, own, x);
 #pragma unroll
     for (int i = 0; i < 4; i++) cur.x[i] = MODE == 1 ? (qa[i] + 2 * x[i]) / 3 : x[i];   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage
-    if (MODE == 1 && mn_out) {
+    if (emit) {
       double y[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) y[i] = cur.x[i] * dn[i];
       cur.mn = quad_min(fmin(fmin(y[0], y[1]), fmin(y[2], y[3])));
       cur.mx = quad_max(fmax(fmax(y[0], y[1]), fmax(y[2], y[3])));
+      stage_bounds(stg_, q, cur.mn, cur.mx);
     }
   };
   if (GA.var_out) {   // the last stage's extra variable (omega_p), DSS'd on read
@@ -917,6 +958,10 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
   for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
   if (q < qsize) { step(q, &A, B); put(B, q); }
   else put(A, q - 1);
+  if (emit) {
+    lds_barrier();
+    flush_bounds(stg_, (qsize - 1) >> 2, GA.pslots, pid.patch, kc / CL, qsize, mn_out, mx_out);
+  }
 }
 
 // DSS of one level field (divdp_proj, eta_dot_dpdn(1:nlev), omega_p): dst = rspheremp * DSS(spheremp * src)
@@ -1232,11 +1277,11 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   double xq[NT][CL];   // Qdp of the levels of the current chunk (fused bounds emission: times dnq = 1/dp of the next step, then min/max)
   double dnq[CL];
   double* const dump_mn = sink + NLEV * 16;
-  double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * qsize;
+  double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * mm_qpad(qsize);
   auto aim = [&](int t, int qq, bool on) __attribute__((always_inline)) {
     col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
     colw[t] = on ? col[t] : sink + p;
-    // bounds of tracer qq at level k: base[(k / CL) * qsize * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
+    // bounds of tracer qq at level k: base[(k / CL) * mm_qpad(qsize) * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
     mnp[t] = on && mn_out ? mn_out + mm_idx(e, qq, 0, qsize) : dump_mn;
     mxp[t] = on && mn_out ? mx_out + mm_idx(e, qq, 0, qsize) : dump_mx;
   };
@@ -1347,7 +1392,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       double mx = fmax(b1 ? m1 : m0, dppq<0x4E>(b1 ? m0 : m1));
       mn = fmin(mn, dppq<0x124>(mn)); mn = fmin(mn, dppq<0x128>(mn));
       mx = fmax(mx, dppq<0x124>(mx)); mx = fmax(mx, dppq<0x128>(mx));
-      const size_t mo = (size_t)((kb + sl0) / CL) * qsize * CL + (b0 ? 2 : 0) + (b1 ? 1 : 0);   // kb, sl0 are multiples of CL
+      const size_t mo = (size_t)((kb + sl0) / CL) * mm_qpad(qsize) * CL + (b0 ? 2 : 0) + (b1 ? 1 : 0);   // kb, sl0 are multiples of CL
       mnp[t][mo] = mn; mxp[t][mo] = mx;   // (the four quads of the row hold and store the same four values)
     }
   };

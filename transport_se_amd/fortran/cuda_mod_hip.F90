@@ -272,8 +272,9 @@ contains
        x_slen(1:ns,1) = slen(1:ns); x_rlen(1:nr,1) = rlen(1:nr)
        call check(tse_halo_minmax_layout(ctx, c_loc(x_slen(1,2)), c_loc(x_rlen(1,2))), 'tse_halo_minmax_layout')
        call check(tse_halo_layout(ctx, ncs, ncr), 'tse_halo_layout')
-       ! largest message: max(qsize*nlev + nlev, 2*qsize*nlev) layers per column
-       allocate(x_hsend(max(1,ncs)*max(qsize*nlev + nlev, 2*qsize*nlev)), x_hrecv(max(1,ncr)*max(qsize*nlev + nlev, 2*qsize*nlev)))
+       ! largest message: max(qsize*nlev + nlev, 2*qpad*nlev) layers per column (the bounds arrays carry the tracer count rounded up
+       ! to a multiple of 4, transport_se_hip.h)
+       allocate(x_hsend(max(1,ncs)*max(qsize*nlev + nlev, 2*((qsize+3)/4*4)*nlev)), x_hrecv(max(1,ncr)*max(qsize*nlev + nlev, 2*((qsize+3)/4*4)*nlev)))
     endif
   end subroutine cuda_mod_init
 
