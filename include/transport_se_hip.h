@@ -164,7 +164,9 @@ int tse_divergence_sphere(tse_ctx *ctx, const double *v, double *div);
 int tse_laplace_sphere_wk(tse_ctx *ctx, const double *s, double *lap);
 int tse_remap_q_ppm(tse_ctx *ctx, double *Qdp, const double *dp1, const double *dp2);
 
-/* qmin/qmax(nlev,qsize,nelemd) module state of prim_advection_mod (:459), for inspection: out[ie][q][k] */
+/* qmin/qmax(nlev,qsize,nelemd) module state of prim_advection_mod (:459), for inspection: out[ie][q][k].  Maintained as in the
+ * reference by tse_euler_step (every stage leaves the bounds its limiter used); tse_advec_tracers_remap_rk2 keeps only what a later
+ * stage reads (nothing reads them after stage 2, stage 3 and the next step recompute theirs) */
 int tse_get_qminmax(tse_ctx *ctx, double *qmin, double *qmax);
 
 /* ---- "next" rows: on-device prescribed fields + device-resident prim_run loop ---- */

@@ -634,8 +634,11 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     // pre-DSS output in the scratch layout (chunks of 4 levels, slots, points perimeter first): what the next stage's blocks
     // load as their own points and as their halo ring
     store_row_pair(Tout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.x);
-    // (stage 3 of the whole-step path: nothing reads the bounds after this stage, the next step starts from fresh ones)
-    if (!NBR && k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
+    // Whole-step path (GIN != 0): nothing reads the bounds after stage 2 or stage 3 -- stage 3 recomputes the element min/max
+    // (prim_advection_mod.F90:796-809: qmin = minval(...), not min(qmin, ...)), the next step starts from fresh ones (:765-779) -- so only
+    // the plain kernels (stage 1 of the whole-step path, whose relaxed bounds stage 2 reuses, :781-793; every stage of the per-stage
+    // API, where qmin/qmax are visible state) write them back
+    if (GIN == 0 && k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
   GatherRaw graw, graw2;
   double2 braw = make_double2(0., 0.);                   // NBR: the lane's piece of the bounds image                                 // raw own / ring loads of the gathered input(s) (DSS on read)
