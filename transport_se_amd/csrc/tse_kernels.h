@@ -215,34 +215,46 @@ __global__ __launch_bounds__(WB * 64) void k_nbr_minmax_patch(int npatch, int qs
     mn[r] = make_double2(0., 0.); mx[r] = mn[r];
     if (e[r] >= 0 && inr) { mn[r] = *reinterpret_cast<const double2*>(in_min + (size_t)e[r] * m + l); mx[r] = *reinterpret_cast<const double2*>(in_max + (size_t)e[r] * m + l); }
   }
+  // the neighbours that are not slots of this patch -- other patches, the received halo -- are loaded and reduced BEFORE the barrier,
+  // with the own values in flight: one memory latency per block instead of two (the block lives for little more than that); min and
+  // max are exact, so the order in which the 9 values meet does not matter
+  double2 a[R], b[R];
+  int lsl[R][8];   // >= 0: neighbour d of slot r is slot lsl of this patch (from LDS, behind the barrier); wave-uniform
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    a[r] = mn[r]; b[r] = mx[r];
+#pragma unroll
+    for (int d = 0; d < 8; d++) {
+      lsl[r][d] = -1;
+      if (e[r] < 0) continue;
+      const int n = nbr[e[r] * 8 + d];   // wave-uniform
+      double2 x = mn[r], y = mx[r];      // no neighbour in this direction
+      if (n >= 0) {
+        const int sl = slot_of[n];
+        if (sl / PS == pi) lsl[r][d] = sl - pi * PS;
+        else if (inr) { x = *reinterpret_cast<const double2*>(in_min + (size_t)n * m + l); y = *reinterpret_cast<const double2*>(in_max + (size_t)n * m + l); }
+      } else if (n <= -2 && inr) {
+        const double* h = recvbuf + (size_t)(-(n + 2)) * nlyr_halo + l;
+        x = *reinterpret_cast<const double2*>(h); y = *reinterpret_cast<const double2*>(h + m);
+      }
+      a[r].x = fmin(a[r].x, x.x); a[r].y = fmin(a[r].y, x.y);
+      b[r].x = fmax(b[r].x, y.x); b[r].y = fmax(b[r].y, y.y);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < R; r++) { smn[w + r * WB][lane] = mn[r]; smx[w + r * WB][lane] = mx[r]; }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; r++) {
     if (e[r] < 0) continue;
-    const bool on = inr;
-    double2 nmn[8], nmx[8];
 #pragma unroll
     for (int d = 0; d < 8; d++) {
-      const int n = nbr[e[r] * 8 + d];   // wave-uniform
-      nmn[d] = mn[r]; nmx[d] = mx[r];    // no neighbour in this direction
-      if (n >= 0) {
-        const int sl = slot_of[n];
-        if (sl / PS == pi) { nmn[d] = smn[sl - pi * PS][lane]; nmx[d] = smx[sl - pi * PS][lane]; }
-        else if (on) { nmn[d] = *reinterpret_cast<const double2*>(in_min + (size_t)n * m + l); nmx[d] = *reinterpret_cast<const double2*>(in_max + (size_t)n * m + l); }
-      } else if (n <= -2 && on) {
-        const double* h = recvbuf + (size_t)(-(n + 2)) * nlyr_halo + l;
-        nmn[d] = *reinterpret_cast<const double2*>(h); nmx[d] = *reinterpret_cast<const double2*>(h + m);
-      }
+      if (lsl[r][d] < 0) continue;
+      const double2 x = smn[lsl[r][d]][lane], y = smx[lsl[r][d]][lane];
+      a[r].x = fmin(a[r].x, x.x); a[r].y = fmin(a[r].y, x.y);
+      b[r].x = fmax(b[r].x, y.x); b[r].y = fmax(b[r].y, y.y);
     }
-    double2 a = mn[r], b = mx[r];
-#pragma unroll
-    for (int d = 0; d < 8; d++) {
-      a.x = fmin(a.x, nmn[d].x); a.y = fmin(a.y, nmn[d].y);
-      b.x = fmax(b.x, nmx[d].x); b.y = fmax(b.y, nmx[d].y);
-    }
-    if (on) { *reinterpret_cast<double2*>(out_min + (size_t)e[r] * m + l) = a; *reinterpret_cast<double2*>(out_max + (size_t)e[r] * m + l) = b; }
+    if (inr) { *reinterpret_cast<double2*>(out_min + (size_t)e[r] * m + l) = a[r]; *reinterpret_cast<double2*>(out_max + (size_t)e[r] * m + l) = b[r]; }
   }
 }
 
