@@ -48,7 +48,9 @@ typedef struct tse_ctx tse_ctx;
  *   kind 0: one entry per edge-buffer column, len[s] = lengthP of the slot (the reference's message layout);
  *   kind 1: the neighbour min/max exchange (viscosity_mod.F90:748-816): the packed fields are element constants, so one
  *           entry per neighbouring (element, direction) pair is sent instead of one per column; len[s] = the number of
- *           shared edges + shared corners with that rank (tse_halo_layout gives the totals). */
+ *           shared edges + shared corners with that rank (tse_halo_layout gives the totals); nlyr = 2 * nlev * (qsize rounded
+ *           up to a multiple of 4): a minimum set and a maximum set in the library's bounds layout, pad tracers included -- a
+ *           callback sizes its buffers by the nlyr it is given. */
 typedef int (*tse_exchange_fn)(void *user, double *sendbuf, double *recvbuf, int nlyr, int kind);
 /* The callback is the portable form of the seam (an MPI host keeps its own communicator: cuda_mod_hip.F90 passes
  * MPI_Isend/Irecv).  The native form is tse_comm_init below: the library then performs the exchange itself with RCCL
