@@ -606,15 +606,16 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
       for (int pi = 0; pi < P.npatch; pi++)
         for (size_t i = 0; i < pt[pi].size(); i++) { pslots[(size_t)pi * psz + i] = pt[pi][i]; tslot_of[pt[pi][i]] = pi * psz + (int)i; }
       std::vector<unsigned> pring((size_t)P.npatch * nrmax, c->zero0());
-      std::vector<unsigned short> plds(nts * 48, (unsigned short)(psz * 16 + nrmax));   // LDS_ZERO of the shape
+      const int lds_ring = psz * 20, lds_zero = lds_ring + nrmax;   // Patch<psz>::LDS_RING, LDS_ZERO
+      std::vector<unsigned short> plds(nts * 48, (unsigned short)lds_zero);
       for (int pi = 0; pi < P.npatch; pi++) {
         std::map<long, int> ring;   // source -> ring entry
         for (size_t i = 0; i < pt[pi].size(); i++) {
           const int e = pt[pi][i];
           for (int k = 0; k < 48; k++) {
             const int2 t = tab[(size_t)e * 48 + k];
-            unsigned short ent = (unsigned short)(psz * 16 + nrmax);
-            if (t.x >= 0 && pid[si][t.x] == pi) ent = (unsigned short)((tslot_of[t.x] - pi * psz) * 16 + t.y);
+            unsigned short ent = (unsigned short)lds_zero;
+            if (t.x >= 0 && pid[si][t.x] == pi) ent = (unsigned short)lds_own_entry(tslot_of[t.x] - pi * psz, t.y);
             else if (t.x != -1) {
               const long key = ring_key(t);
               auto it = ring.find(key);
@@ -624,7 +625,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
                 if (!ab_noring)
                   pring[(size_t)pi * nrmax + it->second] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + ppos(pperm[slot_of[t.x]], t.y) : c->halo0() + (unsigned)(-(t.x + 2));
               }
-              ent = (unsigned short)(psz * 16 + it->second);
+              ent = (unsigned short)(lds_ring + it->second);
             }
             plds[((size_t)pi * psz + i) * 48 + k] = ent;
           }

@@ -41,9 +41,18 @@ template <int PSZ> struct Patch {
   // halo-ring entries (distinct (element, point) pairs outside the patch: 68, 84, 100 for the full shapes; tse_api.hip gives a
   // patch fewer rows if its ring would not fit); lanes 2r, 2r+1 load entry r
   static constexpr int NRMAX = PSZ == 16 ? 96 : PSZ == 24 ? 112 : 128;
-  static constexpr int LDS_ZERO = PSZ * 16 + NRMAX, LDS_ENT = LDS_ZERO + 1;   // entries of one LDS buffer: own points, ring, one all-zero entry
+  // Entries of one LDS buffer (an entry = the CL levels of a point = 32 bytes = 8 of the 64 banks): the own points, the ring, one all-zero
+  // entry.  The own points are SKEWED (lds_own_entry): a slot takes LDS_SLOT = 20 entries instead of 16, and point (j, i) of a slot sits at
+  // position 4j + ((i + j) & 3).  A wave reads, in one ds_read_b64, the same edge of four slots (its rows' neighbour values): in the
+  // natural order an east or west edge is points 3,7,11,15 / 0,4,8,12 -- two bank groups -- and the four slots, 512 bytes apart, fall on
+  // the same two: 8 cycles for the 2 the 512 bytes need.  Skewed, the four points of any edge are in four different groups and slots
+  // s, s+1 in complementary halves of the banks: 2 cycles.  (SQ_LDS_BANK_CONFLICT: more than half of the LDS cycles of the four
+  // gathering kernels before; profiles/r03_ab_lds_skew.txt.)
+  static constexpr int LDS_SLOT = 20;
+  static constexpr int LDS_RING = PSZ * LDS_SLOT, LDS_ZERO = LDS_RING + NRMAX, LDS_ENT = LDS_ZERO + 1;
   static_assert(2 * NRMAX <= THREADS, "one 16-byte ring load per lane");
 };
+__host__ __device__ inline int lds_own_entry(int sl, int p) { return sl * 20 + (p & ~3) + (((p & 3) + (p >> 2)) & 3); }   // (20 = Patch<>::LDS_SLOT)
 inline int patch_nrmax(int psz) { return psz == 16 ? Patch<16>::NRMAX : psz == 24 ? Patch<24>::NRMAX : Patch<32>::NRMAX; }
 struct Scr { size_t tps; unsigned cse; };   // plane stride (doubles), entries per chunk
 // Inside a slot the 16 points are stored in a PER-SLOT order (nibble p of the slot's 64-bit word pperm[slot] = position of
@@ -340,7 +349,7 @@ struct GatherRaw { double2 w[2], r; };   // the lane's two own loads and its rin
 struct RowGather {
   unsigned own, own1;  // plane-relative byte offsets of T[.][kc][slot][pos(j*4 + (odd ? 2 : 0) + {0,1})][kk & ~1]
   unsigned ring;       // plane-relative byte offset of the lane's half of a ring entry
-  unsigned lw, lwr;    // LDS byte offsets (buffer 0) where the lane publishes its first own load / its ring load
+  unsigned lw, lw1, lwr;  // LDS byte offsets (buffer 0) where the lane publishes its two own loads / its ring load
   unsigned lr[5];      // LDS byte offsets (buffer 0) of the lane's five neighbour values
   double rs[4];
 };
@@ -360,7 +369,8 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds<PSZ>& L, con
   const unsigned long long perm = A.pperm[P.slot];
   R.own = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0)) * CL + (kk & ~1)) * 8u;
   R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0 + 1)) * CL + (kk & ~1)) * 8u;
-  R.lw = (unsigned)((sl * 16 + p0) * CL + (kk & ~1)) * 8u;
+  R.lw = (unsigned)(lds_own_entry(sl, p0) * CL + (kk & ~1)) * 8u;
+  R.lw1 = (unsigned)(lds_own_entry(sl, p0 + 1) * CL + (kk & ~1)) * 8u;
   unsigned short le[5];
 #pragma unroll
   for (int m = 0; m < 5; m++) le[m] = A.plds[((size_t)P.tslot * 16 + rw[m] * 4 + pt[m]) * 3 + cn[m]];
@@ -369,7 +379,7 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds<PSZ>& L, con
   const int r = min((int)(threadIdx.x >> 1), NRMAX - 1), half = threadIdx.x & 1;
   const unsigned ent = A.pring[(size_t)P.patch * NRMAX + r];
   R.ring = ((chunk0 + ent) * CL + half * 2) * 8u;
-  R.lwr = (unsigned)((PSZ * 16 + r) * CL + half * 2) * 8u;
+  R.lwr = (unsigned)((Patch<PSZ>::LDS_RING + r) * CL + half * 2) * 8u;
 #pragma unroll
   for (int m = 0; m < 5; m++) R.lr[m] = ((unsigned)le[m] * CL + kk) * 8u;
   load4(A.rspheremp + (size_t)P.e * 16 + j * 4, R.rs);
@@ -391,7 +401,7 @@ __device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds<PSZ>
   const bool odd = k & 1;
   char* base = reinterpret_cast<char*>(&L.v[b][0][0]);
   *reinterpret_cast<double2*>(base + R.lw) = raw.w[0];
-  *reinterpret_cast<double2*>(base + R.lw + CL * 8) = raw.w[1];
+  *reinterpret_cast<double2*>(base + R.lw1) = raw.w[1];
   *reinterpret_cast<double2*>(base + R.lwr) = raw.r;
   const double r0 = swz_xor4(odd ? raw.w[0].x : raw.w[0].y), r1 = swz_xor4(odd ? raw.w[1].x : raw.w[1].y);
   v[0] = odd ? r0 : raw.w[0].x; v[1] = odd ? r1 : raw.w[1].x; v[2] = odd ? raw.w[0].y : r0; v[3] = odd ? raw.w[1].y : r1;
