@@ -191,6 +191,12 @@ int tse_prim_run_subcycle(tse_ctx *ctx, double tstep, int nsub, int *nstep);
  * bit-identical however the elements are distributed; add the elements up with an exact / fixed-order sum for the
  * reference's task-count-independent result (repro_sum's purpose, global_norms_mod.F90:66-68). */
 int tse_element_mass(tse_ctx *ctx, int nt, double *out);
+/* The element shares of the two integrals prim_printstate's "Q<q>,Q diss, dQ^2/dt:" line is made of (prim_state_mod.F90:352-385):
+ * mass[ie][q] = sum_ij spheremp * (sum_k Qdp) and var[ie][q] = sum_ij spheremp * (sum_k Qdp*Q), Q = Qdp/dp with
+ * dp = dhyai*ps0 + dhybi*ps_v(np1) (prim_diag_scalars, :604-655; prim_driver_mod.F90:810-815), operations in the reference's order
+ * (levels inside a point, then the points i fastest as global_integral adds them, global_norms_mod.F90:74-80).
+ * qmin/qmax[ie][q] (may be null) = the element's minimum / maximum of Q, for the "qv=" line (:184-192). */
+int tse_element_qdiag(tse_ctx *ctx, int nt, double *mass, double *var, double *qmin, double *qmax);
 
 /* ---- introspection for tests and the benchmark harness ---- */
 /* device pointers of internal fields: "qdp1", "qdp2" [nelemd][qsize][nlev][16] (the two time levels are two allocations), "vn0", "dp", "divdp", "divdp_proj",

@@ -349,3 +349,37 @@ def test_ragged_sizes(ne, qsize):
     hip.copy_qdp_d2h(elem, 1)
     assert relerr(elem["Qdp"][:, 0], o.qdp[0]) < 10 * TOL_STEP
     hip.close(); o.close()
+
+
+@pytest.mark.parametrize("ne,qsize,alg,generic", [(2, 3, 0, 0), (3, 20, 0, 0), (2, 35, 0, 0), (5, 35, 0, 0), (2, 40, 0, 0), (3, 35, 2, 0), (2, 35, 0, 1)])
+def test_remap_that_assembles_the_last_dss_on_read_leaves_the_bits_of_the_two_kernel_route(monkeypatch, ne, qsize, alg, generic):
+    """Inside tse_prim_run_subcycle the last tracer step of a cycle leaves its stage-3 result pre-DSS and k_remap<.,.,FUSED> assembles
+    rspheremp*DSS(C) and the time average (prim_advection_mod.F90:929-960, 645-662) for its own columns while it reads them
+    (TSE_REMAP_FUSED, default on); TSE_REMAP_FUSED=0 runs k_dss_patch<1> and the in-place remap.  Same contributions in the same
+    order with the same roundings: Qdp, omega_p, dp3d and the next step's cached bounds must agree BIT FOR BIT -- whole sweeps
+    (32 tracers of 35), tracers that go through segment tasks (3 of 35, materialized first), partly idle rounds (20, 40), patches
+    with holes and cube-corner elements (ne 3, 5), vert_remap_q_alg = 2, and the generic column loop (every tracer materialized)."""
+    o = po.Oracle(ne, qsize, nu_q=1e15 * (30.0 / ne) ** 3.2, threads=8)
+    elem = elem_from_oracle(o)
+    dt = 300.0 * 30.0 / ne
+    out = {}
+    monkeypatch.setenv("TSE_REMAP_GENERIC", str(generic))
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TSE_REMAP_FUSED", fused)
+        hip = make_hip(o, elem, vert_remap_q_alg=alg)
+        hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+        assert hip.prim_run_subcycle(dt, 2, 0) == 6
+        out[fused] = dict(qdp=hip.fetch("qdp", (2, o.nelem, qsize, 72, 4, 4)).copy(), omega_p=hip.fetch("omega_p", (o.nelem, 72, 4, 4)).copy(),
+                          dp3d=hip.fetch("dp3d", (o.nelem, 72, 4, 4)).copy())
+        # one more step: it starts from the bounds the remap emitted
+        assert hip.prim_run_subcycle(dt, 1, 6) == 9
+        out[fused]["qdp9"] = hip.fetch("qdp", (2, o.nelem, qsize, 72, 4, 4)).copy()
+        hip.close()
+    for name in out["1"]:
+        a, b = out["1"][name], out["0"][name]
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (name, float(np.abs(a - b).max()))
+    if alg == 0 and not generic:   # and both are the oracle's run
+        o.dcmip_init(1)
+        done, _ = o.prim_run(1, dt, 2)
+        assert done == 6 and relerr(out["1"]["qdp"][0], o.qdp[0]) < 10 * TOL_STEP
+    o.close()

@@ -122,13 +122,15 @@ def test_whole_step_falls_back_when_a_plane_exceeds_32bit_offsets(monkeypatch, c
     same bits as TSE_DSS_ON_READ=0, the step tolerance against the default route, and the library says what it did."""
     import pyoracle as po
     from gpu_common import elem_from_oracle, make_hip, relerr
+    from transport_se_amd import _lib
     o = po.Oracle(ne, q, nu_q=5e17)
     elem = elem_from_oracle(o)
 
     def run(env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        hip = make_hip(o, elem)
+        # (TSE_TEST_* exist only in the -DTSE_AB_HOOKS twin of the library: same sources, same kernels)
+        hip = make_hip(o, elem, lib_path=_lib.HOOKS_SO)
         hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
         assert hip.prim_run_subcycle(900.0, 1, 0) == 3
         out = hip.fetch("qdp", (2, o.nelem, q, 72, 4, 4)).copy()

@@ -162,6 +162,7 @@ def test_ranks_that_cannot_build_a_communicator_fall_back_together(tmp_path):
     import subprocess
     import sys
     import torch
+    from transport_se_amd import _lib
     from transport_se_amd.driver import PrimRun
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one = PrimRun(4, 2, device=0, torch_mod=torch)
@@ -189,6 +190,7 @@ def test_one_rank_failing_its_precheck_takes_every_rank_off_rccl(tmp_path):
     import subprocess
     import sys
     import torch
+    from transport_se_amd import _lib
     from transport_se_amd.driver import PrimRun
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     one = PrimRun(4, 2, device=0, torch_mod=torch)
@@ -198,7 +200,7 @@ def test_one_rank_failing_its_precheck_takes_every_rank_off_rccl(tmp_path):
     w.write_text(_FALLBACK_WORKER)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29635", str(w), root], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
-                       env=dict(os.environ, TSE_TEST_FAIL_PRECHECK_RANK="1"))
+                       env=dict(os.environ, TSE_TEST_FAIL_PRECHECK_RANK="1", TSE_LIB=_lib.HOOKS_SO))   # (fault injection: the -DTSE_AB_HOOKS twin)
     out = r.stdout.decode()
     assert r.returncode == 0, out + r.stderr.decode()[-2000:]
     res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][0][7:])

@@ -47,6 +47,18 @@ def test_namelist_parsing():
     assert s2["nmax"] == 12 * 86400 // 400          # namelist_mod.F90:347-351
     with pytest.raises(SystemExit):
         pm.settings(pm.parse_namelists(NL.replace("limiter_option = 8", "limiter_option = 4")))
+    # the reference's namelist TEMPLATE (placeholders not yet substituted by the run script's sed): a clean abort that says so
+    for tmpl in (NL.replace("ne = 8", "ne = NE"), NL.replace("tstep = 400", "tstep = TIME_STEP")):
+        with pytest.raises(SystemExit, match="placeholders"):
+            pm.settings(pm.parse_namelists(tmpl))
+
+
+def test_fortran_e_format_is_the_references():
+    """prim_printstate writes E23.15 / E22.14 / E15.7 (prim_state_mod.F90:381,389): Fortran puts the mantissa below 1"""
+    assert pm._fortran_e(1.0, 23, 15) == "  0.100000000000000E+01"
+    assert pm._fortran_e(-3.5e-7, 15, 7) == " -0.3500000E-06"
+    assert pm._fortran_e(9.99999999e9, 15, 7) == "  0.1000000E+11"
+    assert pm._fortran_e(0.0, 15, 7) == "  0.0000000E+00"
 
 
 def test_product_diagnostics_agree_with_the_checker():
@@ -123,7 +135,7 @@ def test_preqx_dcmip12_norm_line_equals_the_reference_run(tmp_path):
     stats = open(os.path.join(str(tmp_path), "HommeTime_stats")).read()
     for name in ("prim_run", "prim_advance_exp", "prim_advec_tracers", "vertical_remap"):   # run_ne120_perf.sh:140-144
         assert name in stats
-    assert "qv(2)=" in out
+    assert sum(l.startswith("qv= ") for l in out.splitlines()) >= 4 and "Q2,Q diss, dQ^2/dt:" in out   # prim_printstate's lines (prim_state_mod.F90:341-385)
     for l in out.splitlines():                                    # mass conserved (the "Q,Q diss" check)
         if l.startswith("Q") and "relative change" in l:
             assert abs(float(l.split("relative change")[1].strip(" )"))) < 1e-11
@@ -134,7 +146,7 @@ def test_preqx_prints_the_same_digits_on_1_2_and_4_ranks(tmp_path):
     """norm line, `qv=` lines and tracer-mass lines are string-identical however the sphere is cut (the ranks share the one GPU
     here: TSE_EXCHANGE=staged; on a multi-GPU node the same command runs one rank per GPU over RCCL)"""
     def lines(out):
-        return [l for l in out.splitlines() if l.startswith(("DCMIP", "Q")) and "wall" not in l or "qv(" in l]
+        return [l for l in out.splitlines() if l.startswith(("DCMIP", "Q", "qv= ")) and "wall" not in l]
     nl = NL.replace("nmax = 6             ! six tracer steps", "nmax = 12")
     one = lines(_run_preqx([], nl, tmp_path))
     assert len(one) >= 1 + 4 + 4
@@ -153,7 +165,8 @@ def test_one_rank_meeting_a_negative_layer_thickness_ends_every_rank(tmp_path):
     watchdog -- no hang, no silent success."""
     import time
     env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    env.update(TSE_EXCHANGE="staged", TSE_TEST_FAIL_REMAP_RANK="1", TSE_WATCHDOG_S="150")
+    from transport_se_amd import _lib
+    env.update(TSE_EXCHANGE="staged", TSE_TEST_FAIL_REMAP_RANK="1", TSE_WATCHDOG_S="150", TSE_LIB=_lib.HOOKS_SO)   # (fault injection: the -DTSE_AB_HOOKS twin)
     nl = NL.replace("nmax = 6             ! six tracer steps", "nmax = 12")
     t0 = time.time()
     res = subprocess.run([PREQX, "--gpus", "2"], input=nl.encode(), cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=400)

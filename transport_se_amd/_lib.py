@@ -32,30 +32,66 @@ class InitArgs(C.Structure):
     ]
 
 
-def build(force=False, verbose=False, out=None, flags=()):
-    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  out/flags: an A/B variant of the same sources (tools/ab_build.sh)"""
-    newest = max(os.path.getmtime(p) for p in SRC + [HDR])
-    if out is None and not force and os.path.exists(SO) and os.path.getmtime(SO) >= newest:
-        return SO
-    SO_ = out or SO
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        objs, procs = [], []
-        for name, extra in UNITS:   # the two units compile side by side
-            obj = os.path.join(tmp, name.replace(".hip", ".o"))
-            cmd = ["hipcc"] + CFLAGS + extra + list(flags) + ["-c", "-o", obj, os.path.join(HERE, "csrc", name)]
-            if verbose:
-                print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd))); objs.append(obj)
-        for cmd, p in procs:
-            if p.wait():
-                raise subprocess.CalledProcessError(p.returncode, cmd)
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO_] + objs + \
-              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the in-library bndry_exchangeV (tse_comm_init)
+HOOKS_SO = os.path.join(HERE, "libtransport_se_hip_hooks.so")
+HOOKS_FLAGS = ["-DTSE_AB_HOOKS"]
+
+
+def _compile_units(tmp, tag, flags, verbose):
+    """start the compiler on every translation unit (they run side by side); returns (objs, [(cmd, Popen)])"""
+    objs, procs = [], []
+    for name, extra in UNITS:
+        obj = os.path.join(tmp, tag + name.replace(".hip", ".o"))
+        cmd = ["hipcc"] + CFLAGS + extra + list(flags) + ["-c", "-o", obj, os.path.join(HERE, "csrc", name)]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-    return SO_
+        procs.append((cmd, subprocess.Popen(cmd))); objs.append(obj)
+    return objs, procs
+
+
+def _finish(procs):
+    """wait for EVERY compile before raising (a compiler left running would write into the temporary directory being removed)"""
+    failed = None
+    for cmd, p in procs:
+        if p.wait() and failed is None:
+            failed = subprocess.CalledProcessError(p.returncode, cmd)
+    if failed:
+        raise failed
+
+
+def _link(out, objs, verbose):
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + \
+          ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]   # RCCL: the in-library bndry_exchangeV (tse_comm_init)
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
+def _stale(so):
+    newest = max(os.path.getmtime(p) for p in SRC + [HDR])
+    return not (os.path.exists(so) and os.path.getmtime(so) >= newest)
+
+
+def build(force=False, verbose=False, out=None, flags=(), hooks=True):
+    """hipcc --offload-arch=gfx950 (cross-compiles without a GPU).  Builds the product library and, with hooks=True, its twin with
+    -DTSE_AB_HOOKS (libtransport_se_hip_hooks.so: the A/B switches, the fault injection the tests use, the tse_debug_* entry
+    points -- none of which the product library contains); all translation units compile side by side.
+    out/flags: one A/B variant of the same sources instead (tools/ab_build.sh; always with the hooks)."""
+    import tempfile
+    if out is not None:
+        with tempfile.TemporaryDirectory() as tmp:
+            objs, procs = _compile_units(tmp, "ab_", HOOKS_FLAGS + list(flags), verbose)
+            _finish(procs)
+            _link(out, objs, verbose)
+        return out
+    todo = [(so, fl) for so, fl in ((SO, []), (HOOKS_SO, HOOKS_FLAGS)) if (so == SO or hooks) and (force or _stale(so))]
+    if not todo:
+        return SO
+    with tempfile.TemporaryDirectory() as tmp:
+        started = [(so,) + _compile_units(tmp, "h_" if fl else "p_", fl, verbose) for so, fl in todo]
+        _finish([pr for _, _, procs in started for pr in procs])
+        for so, objs, _ in started:
+            _link(so, objs, verbose)
+    return SO
 
 
 def source_hash():
@@ -67,7 +103,7 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-_lib = None
+_libs = {}
 
 # every symbol include/transport_se_hip.h declares
 SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse_copy_qdp_h2d", "tse_copy_qdp_d2h",
@@ -75,18 +111,19 @@ SYMBOLS = ["tse_init", "tse_finalize", "tse_last_error", "tse_synchronize", "tse
            "tse_qdp_time_avg", "tse_vertical_remap", "tse_get_qminmax", "tse_dcmip_init", "tse_dcmip_set_initial",
            "tse_dcmip_step_inputs", "tse_prim_run_subcycle", "tse_device_ptr", "tse_kernel_time", "tse_timing",
            "tse_halo_layout", "tse_halo_minmax_layout", "tse_comm_unique_id", "tse_comm_init", "tse_comm_precheck", "tse_comm_version", "tse_comm_info", "tse_comm_abort",
-           "tse_boundary_layout", "tse_patch_layout", "tse_placement", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass"]
+           "tse_boundary_layout", "tse_patch_layout", "tse_placement", "tse_invalidate_cache", "tse_divergence_sphere", "tse_laplace_sphere_wk", "tse_remap_q_ppm", "tse_host_register", "tse_element_mass", "tse_element_qdiag"]
 COMM_ID_BYTES = 128
 
 
-def lib():
-    """Load the HIP library; raises (never falls back) if it has not been built."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(SO):
-        raise RuntimeError("libtransport_se_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(there is no CPU fallback for the product path)")
+def lib(path=None):
+    """Load the HIP library; raises (never falls back) if it has not been built.  path (or TSE_LIB): another build of the SAME
+    sources -- the -DTSE_AB_HOOKS twin (HOOKS_SO: fault injection for the tests, A/B switches) or a tools/ab variant -- never a fallback."""
+    path = path or os.environ.get("TSE_LIB", SO)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError("%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)" % os.path.basename(path))
     # One HIP runtime and one RCCL per process.  PyTorch (the control plane of the multi-rank driver, and what the benchmark
     # contract synchronises with) loads the ROCm libraries bundled in its wheel by absolute path; a libamdhip64 / librccl that is
     # already in the process under the same SONAME does not stop it, so "library first, torch later" ends with TWO runtimes
@@ -97,7 +134,7 @@ def lib():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(os.environ.get("TSE_LIB", SO))   # TSE_LIB: A/B builds of the same sources (tools/), never a fallback
+    L = C.CDLL(path)
     vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
     L.tse_init.argtypes = [C.POINTER(vp), C.POINTER(InitArgs)]
     L.tse_finalize.argtypes = [vp]; L.tse_finalize.restype = None
@@ -138,5 +175,6 @@ def lib():
     L.tse_remap_q_ppm.argtypes = [vp, vp, vp, vp]
     L.tse_host_register.argtypes = [vp, vp, sz]
     L.tse_element_mass.argtypes = [vp, i, vp]
-    _lib = L
+    L.tse_element_qdiag.argtypes = [vp, i, vp, vp, vp, vp]
+    _libs[path] = L
     return L

@@ -34,6 +34,17 @@ void launch_advance23(int psz, unsigned blocks, hipStream_t stream, int nelemd, 
 
 // TSE_DSS_ON_READ=0 falls back to one DSS pass per stage in the whole-step call (the per-stage API always does that)
 static bool dss_on_read() { const char* e = getenv("TSE_DSS_ON_READ"); return !(e && e[0] == '0'); }
+// TSE_REMAP_FUSED=0: inside tse_prim_run_subcycle the last step of a cycle runs its own final DSS pass and the remap works in place
+static bool remap_fused() { const char* e = getenv("TSE_REMAP_FUSED"); return !(e && e[0] == '0'); }
+
+// Experiment and fault-injection switches (TSE_AB_*: A/B variants, some of them WRONG on purpose; TSE_TEST_*: failures on request for the
+// tests; the tse_debug_* entry points at the end of this file) exist only in a build with -DTSE_AB_HOOKS
+// (libtransport_se_hip_hooks.so: tools/ab_build.sh, _lib.build_hooks()); the product library does not read them at all.
+#ifdef TSE_AB_HOOKS
+static const char* hook_env(const char* name) { return getenv(name); }
+#else
+static const char* hook_env(const char*) { return nullptr; }
+#endif
 
 static thread_local char g_err[512] = "";
 static int fail(const char* fmt, ...) {
@@ -103,6 +114,7 @@ struct tse_ctx {
   std::vector<hipEvent_t> sync_events; size_t sync_next = 0;
   int *ord_bnd = nullptr, *ord_int = nullptr;
   int n_bnd = 0, n_int = 0;
+  int *rl_all = nullptr, *rl_bnd = nullptr, *rl_int = nullptr;   // the same three element sets in SLOT order: the remap's block lists (k_remap)
   // element patches of the scratch layout (tse_kernels.h): slot = patch*16 + position
   int nslots = 0;
   int* slot_of = nullptr;
@@ -110,6 +122,8 @@ struct tse_ctx {
   int kshape[4] = {16, 16, 16, 16};        // block shape of k_advance<1,1>, k_lap1<1>, k_advance<2,3>, k_dss_patch (patch_shape)
   const PatchSet& set_of(int k) const { return pset[kshape[k] == 32 ? 2 : kshape[k] == 24 ? 1 : 0]; }
   unsigned long long* pperm = nullptr;   // point order inside every slot of the scratch layout
+  unsigned* etab = nullptr;              // [e][16][3] entry (within a chunk) of the DSS contributions of a point: the remap's DSS on read (RemapFuse)
+  int dss_deferred_n0 = 0;               // != 0: the last tracer step left C pre-DSS for the remap to assemble; value = its n0_qdp (tse_prim_run_subcycle only)
   int2* send_src_s = nullptr;   // the send columns in slot space
   unsigned cse = 0;   // entries (points, halo columns) per chunk of a scratch plane
   bool halo() const { return ncol_send || ncol_recv; }
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256) void k_probe_copy(size_t n, const double2* __r
 // (profiles/r03_ab_placement.txt)
 static int place_fields(tse_ctx* c, size_t scr_n, size_t trc) {
   c->place_n = 0;
-  const int budget = getenv("TSE_PLACEMENT") ? atoi(getenv("TSE_PLACEMENT")) : 20;
+  const int budget = std::min(32, getenv("TSE_PLACEMENT") ? atoi(getenv("TSE_PLACEMENT")) : 20);   // (place_bw / tse_placement report 32 tries)
   const double good = getenv("TSE_PLACEMENT_GOOD") ? atof(getenv("TSE_PLACEMENT_GOOD")) : 6000.0;
   const size_t chunk = std::max(scr_n, trc);
   double** role[5] = {&c->T, &c->qlev[0], &c->qlev[1], &c->B, &c->C};
@@ -275,7 +289,15 @@ static int place_fields(tse_ctx* c, size_t scr_n, size_t trc) {
   }
   for (void* p : pads) (void)hipFree(p);
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-  return rc;
+  if (rc) {
+    // the trial ran out of memory or of luck part-way (a chunk given back and its replacement refused: fragmentation, another
+    // process on the device): everything it held is free again -- take the fields as they come, as with TSE_PLACEMENT=0
+    c->place_n = 0;
+    for (double** r : role) *r = nullptr;
+    if (dalloc(&c->qlev[0], trc) || dalloc(&c->qlev[1], trc) || dalloc(&c->T, scr_n) || dalloc(&c->B, scr_n) || dalloc(&c->C, scr_n)) return 1;
+    return 0;
+  }
+  return 0;
 }
 
 static int init_impl(tse_ctx* c, const tse_init_args* a) {
@@ -570,7 +592,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     // its reader two lines.  The points nobody reads from outside fill what is left.
     // TSE_AB_FIXED_PERM=1: the former fixed perimeter-first order (A/B).
     std::vector<unsigned long long> pperm((size_t)c->nslots, 0x67895FEA4DCB3210ULL);
-    if (!(getenv("TSE_AB_FIXED_PERM") && atoi(getenv("TSE_AB_FIXED_PERM")))) {
+    if (!(hook_env("TSE_AB_FIXED_PERM") && atoi(hook_env("TSE_AB_FIXED_PERM")))) {
       static const int edge_dir[4] = {2, 3, 0, 1};   // S, N, W, E as direction indices (west, east, south, north = 0..3)
       for (int e = 0; e < n; e++) {
         int pos_of[16]; bool placed[16] = {false};
@@ -593,7 +615,7 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
         pperm[slot_of[e]] = w;
       }
     }
-    const bool ab_noring = getenv("TSE_AB_NORING") && atoi(getenv("TSE_AB_NORING"));   // A/B: no halo-ring loads at all (WRONG results; bounds what the ring costs)
+    const bool ab_noring = hook_env("TSE_AB_NORING") && atoi(hook_env("TSE_AB_NORING"));   // A/B: no halo-ring loads at all (WRONG results; bounds what the ring costs)
     // ---- the tables of every tiling in use
     for (int si = 0; si < 3; si++) {
       if (!want[si]) continue;
@@ -667,6 +689,22 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     std::vector<int2> send_s(send_src);
     for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(pperm[t.x], t.y); }   // {slot, position within the slot}
     if (upload(&c->slot_of, slot_of) || upload(&c->send_src_s, send_s) || upload(&c->pperm, pperm)) return 1;
+    // the same contributions per ELEMENT as global entries of a chunk, for the remap that assembles the last DSS of a cycle on read
+    std::vector<unsigned> etab((size_t)n * 48);
+    for (size_t i = 0; i < etab.size(); i++) {
+      const int2 t = tab[i];
+      etab[i] = t.x >= 0 ? (unsigned)slot_of[t.x] * 16 + ppos(pperm[slot_of[t.x]], t.y) : t.x == -1 ? c->zero0() : c->halo0() + (unsigned)(-(t.x + 2));
+    }
+    if (upload(&c->etab, etab)) return 1;
+    // the remap's block lists: all / rank-boundary / interior elements in slot order (patch by patch)
+    {
+      std::vector<int> by_slot(n);
+      for (int e = 0; e < n; e++) by_slot[e] = e;
+      std::sort(by_slot.begin(), by_slot.end(), [&](int x, int y) { return slot_of[x] < slot_of[y]; });
+      std::vector<int> rb, ri;
+      for (int e : by_slot) (isb[e] ? rb : ri).push_back(e);
+      if (upload(&c->rl_all, by_slot) || upload(&c->rl_bnd, rb) || upload(&c->rl_int, ri)) return 1;
+    }
   }
 
   // ---- state -------------------------------------------------------------------------------------
@@ -713,6 +751,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipFuncSetAttribute((const void*)k_remap<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
+  HIPCHK(hipFuncSetAttribute((const void*)k_remap<1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RemapLds)));
   HIPCHK(hipDeviceSynchronize());
   return 0;
 }
@@ -726,6 +766,9 @@ int tse_init(tse_ctx** out, const tse_init_args* a) {
     return fail("tse_init: vert_remap_q_alg=%d (0|1: mirrored ghost cells, 2: piecewise-constant boundary cells; control_mod.F90:61-66)", a->vert_remap_q_alg);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("tse_init: no HIP device (this library has no CPU fallback)");
+#ifdef TSE_AB_HOOKS
+  { static bool said = false; if (!said) { fprintf(stderr, "transport_se_hip: this is the TSE_AB_HOOKS build (A/B switches and fault injection enabled) -- not the product library\n"); said = true; } }
+#endif
   tse_ctx* c = new tse_ctx();
   if (init_impl(c, a)) {   // release whatever was allocated before the failure (the message in g_err survives)
     tse_finalize(c);
@@ -748,7 +791,7 @@ void tse_finalize(tse_ctx* c) {
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qorig[0] ? c->qorig[0] : c->qlev[0], c->qorig[0] ? c->qorig[1] : c->qlev[1], c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
-                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm};
+                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm, c->etab, c->rl_all, c->rl_bnd, c->rl_int};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pool.empty()) { for (double* p : {c->T, c->B, c->C}) if (p) (void)hipFree(p); }
   else for (double* p : c->pool) if (p) (void)hipFree(p);
@@ -825,7 +868,7 @@ int tse_comm_precheck(tse_ctx* c, int rank, int nranks) {
   if (nranks < 1 || rank < 0 || rank >= nranks) return fail("tse_comm_precheck: rank %d of %d", rank, nranks);
   for (int p : c->send_peer) if (p < 0 || p >= nranks) return fail("tse_comm_precheck: send peer %d (this is rank %d of %d)", p, rank, nranks);
   for (int p : c->recv_peer) if (p < 0 || p >= nranks) return fail("tse_comm_precheck: recv peer %d (this is rank %d of %d)", p, rank, nranks);
-  if (getenv("TSE_TEST_FAIL_PRECHECK_RANK") && atoi(getenv("TSE_TEST_FAIL_PRECHECK_RANK")) == rank)   // tests: one rank alone is not ready
+  if (hook_env("TSE_TEST_FAIL_PRECHECK_RANK") && atoi(hook_env("TSE_TEST_FAIL_PRECHECK_RANK")) == rank)   // tests: one rank alone is not ready
     return fail("tse_comm_precheck: rank %d fails on request (TSE_TEST_FAIL_PRECHECK_RANK)", rank);
   if (c->halo() && !c->comm_stream) return fail("tse_comm_precheck: no communication stream");
   HIPCHK(hipSetDevice(c->device));
@@ -1305,7 +1348,9 @@ static int join_inputs(tse_ctx* c) {
   c->inputs_pending = false;
   return 0;
 }
-static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp, bool prefetch) {
+// defer_dss: the caller launches the remap next and lets IT assemble the final DSS + time average on read (remap_launch): no
+// k_dss_patch<1> here, Qdp(np1) is not written by this call
+static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n0_qdp, int np1_qdp, bool prefetch, bool defer_dss = false) {
   double* Qn0 = c->q(n0_qdp);
   double* Qnp1 = c->q(np1_qdp);
   const int nq = c->qsize * NLEV;
@@ -1389,6 +1434,11 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
                            c->divdp, c->divdp_proj, c->qmin, c->qmax, c->dp0, gargs(w, c->omega_p, NLEV));   // (tse_stage3.hip)
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_tracers(c, cs, c->C, nqv, nqv) || halo_exchange(c, nqv, 0, cs) || unpack_halo(c, cs, c->C, nqv, nqv); })) return 1;
+  if (defer_dss) {   // C (halo columns filled: the stage's exchange is ordered before the next launch on the compute stream) waits for the remap
+    c->dss_deferred_n0 = n0_qdp;
+    set_bounds_cache(c, 0);
+    return 0;
+  }
   // final DSS fused with qdp_time_avg (:645-662) and with the next step's element min/max
   if (prefetch && c->halo()) {
     hipEvent_t done = nullptr;
@@ -1404,13 +1454,13 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
   return 0;
 }
 
-static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefetch) {
+static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefetch, bool defer_dss = false) {
   if (n0_qdp == np1_qdp || n0_qdp < 1 || n0_qdp > 2 || np1_qdp < 1 || np1_qdp > 2)
     return fail("advec_tracers_remap_rk2: time levels n0_qdp=%d np1_qdp=%d", n0_qdp, np1_qdp);
   bool gor = dss_on_read();
   if (!gor && join_inputs(c)) return 1;
   // gather offsets are 32-bit bytes within a plane; TSE_TEST_PLANE_LIMIT lowers the 4 GiB limit so that tests reach the fallback
-  const size_t plane_limit = getenv("TSE_TEST_PLANE_LIMIT") ? (size_t)strtoull(getenv("TSE_TEST_PLANE_LIMIT"), nullptr, 10) : ((size_t)1 << 32);
+  const size_t plane_limit = hook_env("TSE_TEST_PLANE_LIMIT") ? (size_t)strtoull(hook_env("TSE_TEST_PLANE_LIMIT"), nullptr, 10) : ((size_t)1 << 32);
   if (gor && c->tps * 8 >= plane_limit) {
     static bool said = false;
     if (!said) {
@@ -1427,7 +1477,7 @@ static int advec_step(tse_ctx* c, double dt, int n0_qdp, int np1_qdp, bool prefe
       LAUNCH_CHECK();
       c->t_zero_dirty = false;
     }
-    return advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp, prefetch);   // (sets the bounds cache itself)
+    return advec_dss_on_read(c, dt / 2, n0_qdp, np1_qdp, prefetch, defer_dss);   // (sets the bounds cache itself)
   } else {
     if (tse_compute_divdp(c)) return 1;
     if (euler_step_impl(c, np1_qdp, n0_qdp, dt / 2, 3, 0, false, 0, true)) return 1;
@@ -1447,18 +1497,26 @@ static int remap_launch(tse_ctx* c, double dt, int np1_qdp, bool prefetch) {
   const int nt = getenv("TSE_REMAP_NT") ? atoi(getenv("TSE_REMAP_NT")) : 1;
   const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
   double* Qr = c->q(np1_qdp);
+  // the tracer step before left its final DSS + time average to this launch (advec_dss_on_read, defer_dss): Qr is written only
+  const int fused_n0 = c->dss_deferred_n0;
+  c->dss_deferred_n0 = 0;
+  if (fused_n0 && (fused_n0 == np1_qdp || nt != 1)) return fail("vertical_remap: deferred DSS of time level %d cannot be assembled here", fused_n0);
+  RemapFuse F{};
+  if (fused_n0) F = RemapFuse{c->C, c->scr(), c->etab, c->slot_of, c->pperm, c->q(fused_n0), c->rspheremp, c->omega_p, c->zero0()};
   auto launch = [&](Work w) -> int {   // block = element
     if (!w.nwork) return 0;
+    const int* list = w.order == c->ord_bnd ? c->rl_bnd : w.order == c->ord_int ? c->rl_int : c->rl_all;   // the same elements, in slot order
     auto go = [&](auto kern, int threads) {
-      hipLaunchKernelGGL(kern, dim3(w.nwork), dim3(threads), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
-                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, w.order, c->lvl_tmp);
+      hipLaunchKernelGGL(kern, dim3(8 * ((w.nwork + 7) / 8)), dim3(threads), sizeof(RemapLds), c->stream, c->qsize, dt, c->ps0, c->hyai, c->hybi,
+                         c->dp, c->divdp_proj, c->dp3d, c->ps_v, Qr, c->bad, c->qmin2, c->qmax2, generic, c->sink, (const double*)nullptr, list, w.nwork, c->lvl_tmp, F);
     };
-    if (nt == 1) { if (c->remap_alg2) go(k_remap<1, true>, REMAP_THREADS); else go(k_remap<1, false>, REMAP_THREADS); }
+    if (fused_n0) { if (c->remap_alg2) go(k_remap<1, true, true>, REMAP_THREADS); else go(k_remap<1, false, true>, REMAP_THREADS); }
+    else if (nt == 1) { if (c->remap_alg2) go(k_remap<1, true>, REMAP_THREADS); else go(k_remap<1, false>, REMAP_THREADS); }
     else { if (c->remap_alg2) go(k_remap<2, true>, REMAP_THREADS / 2); else go(k_remap<2, false>, REMAP_THREADS / 2); }
     LAUNCH_CHECK();
     return 0;
   };
-  if (getenv("TSE_TEST_FAIL_REMAP")) {   // tests: this process's remap reports a negative layer thickness (one rank of several failing alone)
+  if (hook_env("TSE_TEST_FAIL_REMAP")) {   // tests: this process's remap reports a negative layer thickness (one rank of several failing alone)
     static const int one = 1;
     HIPCHK(hipMemcpyAsync(c->bad, &one, sizeof(int), hipMemcpyHostToDevice, c->stream));
   }
@@ -1531,9 +1589,9 @@ int tse_remap_q_ppm(tse_ctx* c, double* Qdp, const double* dp1, const double* dp
         hipMemcpy(d2, dp2, lev * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemset(c->divdp_proj, 0, lev * 8) != hipSuccess) { rc = fail("tse_remap_q_ppm: upload failed"); break; }
     const int generic = getenv("TSE_REMAP_GENERIC") ? atoi(getenv("TSE_REMAP_GENERIC")) : 0;
     auto go = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(c->nelemd), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
+      hipLaunchKernelGGL(kern, dim3(8 * ((c->nelemd + 7) / 8)), dim3(REMAP_THREADS), sizeof(RemapLds), c->stream, c->qsize, 0.0, c->ps0, c->hyai, c->hybi,
                          c->dp, c->divdp_proj, c->dp3d, c->ps_v, c->q(1), c->bad, (double*)nullptr, (double*)nullptr, generic, c->sink, (const double*)d2,
-                         (const int*)nullptr, c->lvl_tmp);
+                         (const int*)nullptr, c->nelemd, c->lvl_tmp, RemapFuse{});
     };
     if (c->remap_alg2) go(k_remap<1, true>); else go(k_remap<1, false>);
     if (hipGetLastError() != hipSuccess) { rc = fail("tse_remap_q_ppm: kernel launch failed"); break; }
@@ -1556,6 +1614,25 @@ int tse_element_mass(tse_ctx* c, int nt, double* out) {
   int rc = 0;
   if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out, d, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("tse_element_mass: launch or copy failed");
+  (void)hipFree(d);
+  return rc;
+}
+
+// per-element shares of Qmass = integral(sum_k Qdp) and Qvar = integral(sum_k Qdp*Q) of time level nt (prim_diag_scalars,
+// prim_state_mod.F90:604-655, with the ps_v the last remap left) -> host mass_out, var_out [nelemd][qsize]
+int tse_element_qdiag(tse_ctx* c, int nt, double* mass_out, double* var_out, double* min_out, double* max_out) {
+  if (nt < 1 || nt > 2 || !mass_out || !var_out) return fail("tse_element_qdiag: nt=%d", nt);
+  const size_t n = (size_t)c->nelemd * c->qsize;
+  double* d = nullptr;
+  if (dalloc(&d, 4 * n)) return 1;
+  hipLaunchKernelGGL(k_elem_qdiag<>, dim3((unsigned)n), dim3(64), 0, c->stream, c->qsize, (const double*)(c->q(nt)), (const double*)c->spheremp,
+                     (const double*)c->ps_v, (const double*)c->hyai, (const double*)c->hybi, c->ps0, d, d + n, d + 2 * n, d + 3 * n);
+  int rc = hipGetLastError() != hipSuccess;
+  double* outs[4] = {mass_out, var_out, min_out, max_out};
+  for (int i = 0; i < 4 && !rc; i++)
+    if (outs[i]) rc = hipMemcpyAsync(outs[i], d + i * n, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess;
+  if (!rc) rc = hipStreamSynchronize(c->stream) != hipSuccess;
+  if (rc) rc = fail("tse_element_qdiag: launch or copy failed");
   (void)hipFree(d);
   return rc;
 }
@@ -1625,6 +1702,8 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
     return 2;
   };
   const bool overlap_inputs = !(getenv("TSE_INPUT_OVERLAP") && getenv("TSE_INPUT_OVERLAP")[0] == '0');
+  // the remap that closes the cycle assembles the last step's final DSS + time average on read (TSE_REMAP_FUSED=0: two kernels)
+  const bool fuse_remap = remap_fused() && dss_on_read() && c->tps * 8 < ((size_t)1 << 32) && !(getenv("TSE_REMAP_NT") && atoi(getenv("TSE_REMAP_NT")) != 1);
   for (int s = 0; s < nsub; s++) {
     if (s >= 2) {
       HIPCHK(hipEventSynchronize(c->bad_ev[s & 1]));
@@ -1640,7 +1719,7 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
         c->inputs_pending = true;   // joined by the step before its first kernel that reads them (join_inputs)
       } else if (tse_dcmip_step_inputs(c, nstep, tstep)) return 1;
       if (nstep % 2 == 0) { n0 = 1; np1 = 2; } else { n0 = 2; np1 = 1; }  // TimeLevel_Qdp, time_mod.F90:85-109
-      if (advec_step(c, tstep, n0, np1, r + 1 < c->rsplit)) return 1;   // (the remap follows the last one: its bounds would be stale)
+      if (advec_step(c, tstep, n0, np1, r + 1 < c->rsplit, fuse_remap && r + 1 == c->rsplit)) return 1;   // (the remap follows the last one: its bounds would be stale)
       nstep++;
     }
     if (remap_launch(c, tstep * c->rsplit, np1, true)) { *nstep_io = nstep; return 1; }
@@ -1670,6 +1749,7 @@ void* tse_device_ptr(tse_ctx* c, const char* name, size_t* nbytes) {
   if (nbytes) *nbytes = 0;
   return nullptr;
 }
+#ifdef TSE_AB_HOOKS
 // ---- developer experiment: where the scratch fields live (tools/placement_probe.py) ------------------------------------------
 // make the pool K scratch-sized allocations (the first three are T, B, C as allocated)
 extern "C" int tse_debug_scratch_pool(tse_ctx* c, int K) {
@@ -1722,6 +1802,7 @@ extern "C" int tse_debug_probe(tse_ctx* c, int src, int dst, double* gbps) {
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   return 0;
 }
+#endif   // TSE_AB_HOOKS
 int tse_timing(tse_ctx* c, int enable) { resolve_timers(c); c->timing = enable != 0; c->timers.clear(); return 0; }
 int tse_kernel_time(tse_ctx* c, const char* name, double* ms, long* launches) {
   resolve_timers(c);

@@ -157,6 +157,41 @@ __global__ __launch_bounds__(128) void k_elem_mass(int qsize, const double* __re
   }
 }
 
+// The element's share of the two integrals behind the "Q<q>,Q diss, dQ^2/dt:" line of prim_printstate (prim_state_mod.F90:352-385):
+// prim_diag_scalars (:604-655) forms, per point, Qmass = sum_k Qdp and Qvar = sum_k Qdp*Q with Q = Qdp/dp,
+// dp = (hyai(k+1)-hyai(k))*ps0 + (hybi(k+1)-hybi(k))*ps_v (prim_driver_mod.F90:810-815), and global_integral
+// (global_norms_mod.F90:74-80) adds da*h over the element's points, i fastest.  Same operations in the same order (no contraction), so
+// that an element's partial is a fixed number whatever computes it.  block = (element, tracer); lanes 0..15 = points.
+template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
+__global__ __launch_bounds__(64) void k_elem_qdiag(int qsize, const double* __restrict__ Q, const double* __restrict__ spheremp, const double* __restrict__ ps_v,
+                                                   const double* __restrict__ hyai, const double* __restrict__ hybi, double ps0,
+                                                   double* __restrict__ mass_out, double* __restrict__ var_out,
+                                                   double* __restrict__ min_out, double* __restrict__ max_out /* element min/max of Q (the qv= line, :184-192) */) {
+#pragma clang fp contract(off)
+  __shared__ double hm[16], hv[16], hn[16], hx[16];
+  const int e = blockIdx.x / qsize, q = blockIdx.x - e * qsize, p = threadIdx.x;
+  if (p < 16) {
+    const double* x = Q + ((size_t)e * qsize + q) * NLEV * 16 + p;
+    const double ps = ps_v[(size_t)e * 16 + p];
+    double m = 0.0, v = 0.0, mn = 1e300, mx = -1e300;
+    for (int k = 0; k < NLEV; k++) {
+      const double dpk = (hyai[k + 1] - hyai[k]) * ps0 + (hybi[k + 1] - hybi[k]) * ps;
+      const double qd = x[(size_t)k * 16], qq = qd / dpk;
+      m = m + qd;
+      v = v + qd * qq;
+      mn = fmin(mn, qq); mx = fmax(mx, qq);
+    }
+    hm[p] = m; hv[p] = v; hn[p] = mn; hx[p] = mx;
+  }
+  __syncthreads();
+  if (p == 0) {
+    const double* w = spheremp + (size_t)e * 16;
+    double jm = 0.0, jv = 0.0, mn = hn[0], mx = hx[0];
+    for (int i = 0; i < 16; i++) { jm = jm + w[i] * hm[i]; jv = jv + w[i] * hv[i]; mn = fmin(mn, hn[i]); mx = fmax(mx, hx[i]); }
+    mass_out[blockIdx.x] = jm; var_out[blockIdx.x] = jv; min_out[blockIdx.x] = mn; max_out[blockIdx.x] = mx;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // element min/max of Q = Qdp/dp, dp = derived%dp - rhs_multiplier*dt*divdp_proj  (prim_advection_mod.F90:750-775)
 template <int = 0>   // (a template only so that two translation units can include this header: tse_stage3.hip)
@@ -1194,6 +1229,131 @@ __device__ __forceinline__ void ppm_zterms(double x2, double& z1, double& zz2, d
 __device__ __forceinline__ double ppm_integ(double c0, double c1, double c2, double z1, double zz2, double z3) {
   return fma(c2 * z3, 1.0 / 3.0, fma(c1, zz2, c0 * z1));
 }
+// ---- DSS + time average ON READ (the remap that closes an rsplit cycle inside tse_prim_run_subcycle) ----------------------------
+// The last tracer step of a cycle leaves its stage-3 result C pre-DSS in the scratch layout and launches no k_dss_patch<1>: the remap
+// assembles Qdp(np1) = (Qdp(n0) + 2 * rspheremp * DSS(C)) / 3 (prim_advection_mod.F90:929-960 + :645-662) for its own columns while it
+// reads them, and writes the REMAPPED field -- the write of the DSS pass and the read of the remap (2/3 of a field pass per step at
+// rsplit = 3) never happen.  Same contributions, same order (S, E, N, W edges, then the corner), same roundings as gather_sum +
+// k_dss_patch<1>: the same bits as the two-kernel route (tests/test_gpu_parity.py).
+// A column thread (tracer q, point p) loads, per chunk of 4 levels, its own entry (32 bytes), two neighbour entries and the 4 values
+// of Qdp(n0).  Of a slab's 20 neighbour values an interior point needs none, an edge point one, a corner three: the corner's diagonal
+// term is fetched by the edge lane next to it (lanes 1, 2, 13, 14 of the 16 -- their second slot is free) and handed over with one
+// quad_perm DPP move, as in gather_sum; absent contributions point at the all-zero slot.
+struct RemapFuse {
+  const double* C;                 // stage-3 scratch, halo columns filled (null: plain remap of Q in place)
+  Scr S;
+  const unsigned* etab;            // [e][16][3]: entry (within a chunk) of the DSS contributions of point p, in the reference's order; absent = the zero slot
+  const int* slot_of;
+  const unsigned long long* pperm;
+  const double* Qn0;               // Qdp(n0), standard layout
+  const double* rspheremp;
+  double* var_out;                 // omega_p <- rspheremp * DSS(plane qsize of C)  (prim_advection_mod.F90:943-957), may be null
+  unsigned zero0;                  // entry of the all-zero slot
+};
+#ifndef TSE_FUSE_DIAG
+#define TSE_FUSE_DIAG 0
+#endif
+struct FuseLane { unsigned oown, oa, ob; double rs; bool corner; };
+struct FuseRaw { double2 o[2], a[2], b[2]; double q[CL]; };
+__device__ __forceinline__ FuseLane fuse_lane(const RemapFuse& F, int e, int p) {
+  FuseLane L;
+  const int s = F.slot_of[e];
+  const unsigned* et = F.etab + (size_t)e * 48;
+  L.oown = ((unsigned)s * 16 + ppos(F.pperm[s], p)) * (CL * 8u);
+  L.oa = et[p * 3] * (CL * 8u);
+  L.corner = (p == 0) | (p == 3) | (p == 12) | (p == 15);
+  const int pc = p == 1 ? 0 : p == 2 ? 3 : p == 13 ? 12 : p == 14 ? 15 : -1;   // the corner whose diagonal term this lane fetches
+  L.ob = (L.corner ? et[p * 3 + 1] : pc >= 0 ? et[pc * 3 + 2] : F.zero0) * (CL * 8u);
+  L.rs = F.rspheremp[(size_t)e * 16 + p];
+  return L;
+}
+// the loads of chunk kc of one tracer column: plane = &C[q][0] as bytes, q0col = &Qn0[e][q][0][p]
+__device__ __forceinline__ void fuse_issue(FuseRaw& r, const char* __restrict__ plane, unsigned cstride /* bytes per chunk */, int kc, const FuseLane& L,
+                                           const double* __restrict__ q0col) {
+  const char* b = plane + (size_t)kc * cstride;
+  r.o[0] = *reinterpret_cast<const double2*>(b + L.oown); r.o[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
+#if TSE_FUSE_DIAG & 1   // A/B (WRONG results): no ring traffic, same instructions
+  r.a[0] = *reinterpret_cast<const double2*>(b + L.oown);   r.a[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
+  r.b[0] = *reinterpret_cast<const double2*>(b + L.oown);   r.b[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
+#elif TSE_FUSE_DIAG & 8   // A/B (WRONG results): no neighbour loads at all
+  r.a[0] = r.a[1] = r.b[0] = r.b[1] = make_double2(0., 0.);
+#else
+  r.a[0] = *reinterpret_cast<const double2*>(b + L.oa);   r.a[1] = *reinterpret_cast<const double2*>(b + L.oa + 16);
+  r.b[0] = *reinterpret_cast<const double2*>(b + L.ob);   r.b[1] = *reinterpret_cast<const double2*>(b + L.ob + 16);
+#endif
+#pragma unroll
+#if TSE_FUSE_DIAG & 2   // A/B (WRONG results): no Qdp(n0) stream
+  for (int i = 0; i < CL; i++) r.q[i] = 1.0;
+#else
+  for (int i = 0; i < CL; i++) r.q[i] = q0col[(size_t)(kc * CL + i) * 16];
+#endif
+}
+// (all four lanes of a quad call it together: the hand-over of the corner's diagonal term is a DPP move)
+__device__ __forceinline__ void fuse_combine(const FuseRaw& r, const FuseLane& L, double cur[CL]) {
+  const double o[CL] = {r.o[0].x, r.o[0].y, r.o[1].x, r.o[1].y}, a[CL] = {r.a[0].x, r.a[0].y, r.a[1].x, r.a[1].y},
+               b[CL] = {r.b[0].x, r.b[0].y, r.b[1].x, r.b[1].y};
+#pragma unroll
+  for (int i = 0; i < CL; i++) {
+    const double d = dppq<0xA5>(b[i]);   // quad_perm [1,1,2,2]: lanes 0 and 3 of the quad receive what lanes 1 and 2 fetched for them
+    double t = o[i] + a[i];
+    t = L.corner ? (t + b[i]) + d : t;
+#if TSE_FUSE_DIAG & 4   // A/B (last bits differ): no division
+    cur[i] = fma(2.0, L.rs * t, r.q[i]) * (1.0 / 3.0);
+#else
+    cur[i] = fma(2.0, L.rs * t, r.q[i]) / 3.0;   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage, rkstage = 3
+#endif
+  }
+}
+// Qout[e][q][.][.] = (Qdp(n0) + 2*rspheremp*DSS(C))/3 for the tracers q0 <= q < q1 of element e, and var_out <- rspheremp*DSS(plane qsize)
+// if asked for: all threads of the block; thread = (plane, chunk, point), all three contributions loaded by the thread itself.  Used for
+// what the sweeps do not assemble on read: the tracers that go through segment tasks, the extra plane, and every tracer of an element
+// that takes the generic column loop.
+__device__ __forceinline__ void fuse_materialize(const RemapFuse& F, int e, int qsize, int q0, int q1, bool var, double* __restrict__ Qout, int tid, int nthreads) {
+  const int s = F.slot_of[e];
+  const unsigned long long perm = F.pperm[s];
+  const unsigned cstride = F.S.cse * (CL * 8u);
+  const int nplane = (q1 - q0) + (var && F.var_out ? 1 : 0), nitem = nplane * NCHUNK * 16;
+  constexpr int U = 5;   // items per thread in flight: the 3 + 1 planes of the usual case (35 tracers, 16 tracer slots) are 4.5 items per thread -- one memory round trip
+  for (int w0 = tid; w0 < nitem; w0 += U * nthreads) {
+    double2 v[U][4][2]; double qn[U][CL];
+    int pl[U], kc[U], pt[U]; bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int w = w0 + u * nthreads;
+      on[u] = w < nitem;
+      const int ww = on[u] ? w : tid;
+      pt[u] = ww & 15; kc[u] = (ww >> 4) % NCHUNK; pl[u] = (ww >> 4) / NCHUNK;
+      const bool isvar = q0 + pl[u] >= q1;
+      const int q = isvar ? qsize : q0 + pl[u];
+      const char* b = reinterpret_cast<const char*>(F.C + (size_t)q * F.S.tps) + (size_t)kc[u] * cstride;
+      const unsigned* et = F.etab + ((size_t)e * 16 + pt[u]) * 3;
+      const unsigned ent[4] = {(unsigned)s * 16 + ppos(perm, pt[u]), et[0], et[1], et[2]};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        v[u][c][0] = *reinterpret_cast<const double2*>(b + ent[c] * (CL * 8u));
+        v[u][c][1] = *reinterpret_cast<const double2*>(b + ent[c] * (CL * 8u) + 16);
+      }
+#pragma unroll
+      for (int i = 0; i < CL; i++) qn[u][i] = isvar ? 0.0 : F.Qn0[(((size_t)e * qsize + q) * NLEV + kc[u] * CL + i) * 16 + pt[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      if (!on[u]) continue;
+      const bool isvar = q0 + pl[u] >= q1;
+      const double rs = F.rspheremp[(size_t)e * 16 + pt[u]];
+#pragma unroll
+      for (int i = 0; i < CL; i++) {
+        const int h = i >> 1;
+        const double o = (i & 1) ? v[u][0][h].y : v[u][0][h].x, c0 = (i & 1) ? v[u][1][h].y : v[u][1][h].x,
+                     c1 = (i & 1) ? v[u][2][h].y : v[u][2][h].x, c2 = (i & 1) ? v[u][3][h].y : v[u][3][h].x;
+        const double x = rs * (((o + c0) + c1) + c2);
+        if (isvar) F.var_out[((size_t)e * NLEV + kc[u] * CL + i) * 16 + pt[u]] = x;
+        else Qout[(((size_t)e * qsize + q0 + pl[u]) * NLEV + kc[u] * CL + i) * 16 + pt[u]] = fma(2.0, x, qn[u][i]) / 3.0;
+      }
+    }
+  }
+}
+
 // Generic column loop (any kid(k) >= k-1): thread = (tracer, column) walks down the column, advancing a 5-cell window by a
 // data-dependent number of cells per level (compute_ppm :267-342, integrate_parabola :349-356, mass differencing :203-209).
 // Only taken by elements whose Lagrangian interfaces moved by more than one layer somewhere (see k_remap).
@@ -1286,16 +1446,27 @@ __device__ __forceinline__ void remap_columns_generic(const RemapLds& S, double*
 // in the order of the sweep), primes the 5-cell window from the cells around its first level with the formulas of the
 // sweep, runs the level before its first one with the stores turned into a dump (that yields the running new-grid mass), and
 // then its REMAP_PF levels: the same values in the same order as a whole sweep produces.
-template <int NT, bool ALG2>
+template <int NT, bool ALG2, bool FUSED = false>
 __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __restrict__ Q, int e, int qsize, int tid, int nthreads,
                                                    double* __restrict__ mn_out, double* __restrict__ mx_out, double* __restrict__ sink,
-                                                   const double* __restrict__ rdpg /* [k][p]: 1/dp of the next step (bounds emission) */) {
+                                                   const double* __restrict__ rdpg /* [k][p]: 1/dp of the next step (bounds emission) */,
+                                                   const RemapFuse& F = RemapFuse{}) {
+  static_assert(!FUSED || NT == 1, "DSS on read: one tracer per thread");
   const int p = tid & 15, slots = (nthreads >> 4) * NT;
+  // FUSED: the whole sweeps read (Qdp(n0) + 2*rspheremp*DSS(C))/3 assembled on the fly (fuse_issue / fuse_combine: one chunk of 4 levels
+  // in flight while the one before is consumed) and write Q = Qdp(np1); the segment tasks run in place on tracers the kernel has
+  // materialized in Q beforehand (k_remap)
+  FuseLane FL{};
+  FuseRaw fraw;
+  double fcur[CL] = {0, 0, 0, 0};
+  const char* fplane = nullptr;
+  const unsigned fcstride = FUSED ? F.S.cse * (CL * 8u) : 0u;
+  if (FUSED) FL = fuse_lane(F, e, p);
   // The level body below is free of branches and predicated stores, so that the 8 levels of an unrolled block form one
   // basic block and the scheduler can overlap the dependency chains of neighbouring levels.  A surplus tracer slot of the
   // NT = 2 form (q >= qsize) therefore reads the last tracer and writes into `sink`; the element min/max is stored by all 16
   // lanes of the row (same value).
-  double* col[NT];
+  const double* col[NT];
   double *colw[NT], *mnp[NT], *mxp[NT];
   double pf[NT][REMAP_PF];
   double ak[NT], ak1[NT], ak2[NT], mk[NT], mk1[NT], mk2[NT], dmak1[NT], aikm1[NT], aik[NT], masso[NT], massn1[NT];
@@ -1303,20 +1474,29 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   double dnq[CL];
   double* const dump_mn = sink + NLEV * 16;
   double* const dump_mx = sink + NLEV * 16 + (size_t)NLEV * mm_qpad(qsize);
-  auto aim = [&](int t, int qq, bool on) __attribute__((always_inline)) {
-    col[t] = Q + ((size_t)e * qsize + qq) * NLEV * 16 + p;
-    colw[t] = on ? col[t] : sink + p;
+  auto aim = [&](int t, int qq, bool on, auto fused_tag) __attribute__((always_inline)) {
+    col[t] = (decltype(fused_tag)::value ? F.Qn0 : Q) + ((size_t)e * qsize + qq) * NLEV * 16 + p;   // fused: the column of Qdp(n0)
+    colw[t] = on ? Q + ((size_t)e * qsize + qq) * NLEV * 16 + p : sink + p;
+    if (decltype(fused_tag)::value) fplane = reinterpret_cast<const char*>(F.C + (size_t)qq * F.S.tps);
     // bounds of tracer qq at level k: base[(k / CL) * mm_qpad(qsize) * CL + k % CL] (mm_idx); the dump areas of `sink` take the same offsets
     mnp[t] = on && mn_out ? mn_out + mm_idx(e, qq, 0, qsize) : dump_mn;
     mxp[t] = on && mn_out ? mx_out + mm_idx(e, qq, 0, qsize) : dump_mx;
   };
   // window at the top of the column: a(0) = a(1), a(-1) = a(2)
-  auto prime_top = [&]() __attribute__((always_inline)) {
+  auto prime_top = [&](auto fused_tag) __attribute__((always_inline)) {
+    if constexpr (decltype(fused_tag)::value) {   // chunk 0 -> cells 1 .. 4 (the fourth waits in fcur[3]); chunk 1 on its way
+      fuse_issue(fraw, fplane, fcstride, 0, FL, col[0]);
+      fuse_combine(fraw, FL, fcur);
+      mk[0] = fcur[0]; mk1[0] = fcur[1]; mk2[0] = fcur[2];
+      asm volatile("" : "+v"(fcur[3]) : : "memory");   // (the values have left fraw before the next loads are issued into it)
+      fuse_issue(fraw, fplane, fcstride, 1, FL, col[0]);
+    } else {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
       mk[t] = col[t][0]; mk1[t] = col[t][16]; mk2[t] = col[t][32];
 #pragma unroll
       for (int r = 0; r < REMAP_PF; r++) pf[t][r] = col[t][(size_t)(r + 3) * 16];   // cells 4 .. 3+REMAP_PF
+    }
     }
     const double r1 = S.rdpo[2][p], r2 = S.rdpo[3][p], r3 = S.rdpo[4][p];
 #pragma unroll
@@ -1357,18 +1537,36 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
     if (!TAIL || k + 3 <= NLEV) v.rr = brdpo[(sl + 5) * 16];   // rdpo[r + 1], r = k + 3
     return v;
   };
-  auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl, auto reload_tag) __attribute__((always_inline)) {
+  auto level = [&](auto tail_tag, auto emit_tag, int kb, int sl, auto reload_tag, auto fused_tag) __attribute__((always_inline)) {
     constexpr bool TAIL = decltype(tail_tag)::value, EMIT = decltype(emit_tag)::value, RELOAD = decltype(reload_tag)::value;   // RELOAD: keep the FIFO filled
+    constexpr bool FZ = decltype(fused_tag)::value;
     const int k = kb + sl + 1, r = k + 3;   // level being written, cell entering the window
-    const LevelOps c = nxt;
-    nxt = fetch(tail_tag, kb, sl + 1);
+    // (FUSED: the level fetches its own operands -- the one-level lookahead costs 16 registers the chunk in flight needs: with it the
+    // kernel spills inside the level loop, without it 9 registers are parked once per sweep)
+    LevelOps c;
+    if (FZ) c = fetch(tail_tag, kb, sl);
+    else { c = nxt; nxt = fetch(tail_tag, kb, sl + 1); }
     double ak3[NT], mk3[NT];
     if (!TAIL || r <= NLEV) {
+      if constexpr (FZ) {
+        // cell r is level (sl + 3) & 3 of chunk (r - 1) / CL (kb is a multiple of REMAP_PF): a new chunk starts at sl = 1, 5 -- its loads were
+        // issued four levels ago; combine them and send for the next chunk
+        const int ci = (sl + 3) & (CL - 1);
+        if (ci == 0) {
+          fuse_combine(fraw, FL, fcur);
+          asm volatile("" : "+v"(fcur[0]), "+v"(fcur[1]), "+v"(fcur[2]), "+v"(fcur[3]) : : "memory");
+          const int kn = (r - 1) / CL + 1;
+          if (!TAIL || kn < NCHUNK) fuse_issue(fraw, fplane, fcstride, kn, FL, col[0]);
+        }
+        mk3[0] = fcur[ci];
+        ak3[0] = mk3[0] * c.rr;
+      } else {
 #pragma unroll
       for (int t = 0; t < NT; t++) {
         mk3[t] = pf[t][sl];
         if (RELOAD && (!TAIL || r + REMAP_PF <= NLEV)) pf[t][sl] = col[t][(size_t)(r + REMAP_PF - 1) * 16];
         ak3[t] = mk3[t] * c.rr;
+      }
       }
     } else {
 #pragma unroll
@@ -1422,7 +1620,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
     }
   };
   // scheduler fence every 4 levels (fences every 2 or 8 levels: same time; 244 instead of 212 registers without)
-  auto block = [&](auto tail_tag, auto emit_tag, int kb, auto reload_tag) __attribute__((always_inline)) {
+  auto block = [&](auto tail_tag, auto emit_tag, int kb, auto reload_tag, auto fused_tag) __attribute__((always_inline)) {
     bases(kb);
 #pragma unroll
     for (int sl = 0; sl < REMAP_PF; sl++) {
@@ -1430,14 +1628,15 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 #pragma unroll
         for (int i = 0; i < CL; i++) dnq[i] = rdpg[(kb + sl + i) * 16 + p];
       }
-      level(tail_tag, emit_tag, kb, sl, reload_tag);
+      level(tail_tag, emit_tag, kb, sl, reload_tag, fused_tag);
       if (sl % CL == CL - 1) { if (decltype(emit_tag)::value) emit4(kb, sl - (CL - 1)); __builtin_amdgcn_sched_barrier(0); }
     }
   };
   constexpr int CLEAN = NLEV - 2 * REMAP_PF;   // blocks starting below this never see a ghost cell or an empty FIFO slot
+  using FusedTag = std::integral_constant<bool, FUSED>;
   auto column = [&](auto emit_tag) __attribute__((always_inline)) {
-    for (int kb = 0; kb < CLEAN; kb += REMAP_PF) block(std::false_type{}, emit_tag, kb, std::true_type{});
-    for (int kb = CLEAN; kb < NLEV; kb += REMAP_PF) block(std::true_type{}, emit_tag, kb, std::true_type{});
+    for (int kb = 0; kb < CLEAN; kb += REMAP_PF) block(std::false_type{}, emit_tag, kb, std::true_type{}, FusedTag{});
+    for (int kb = CLEAN; kb < NLEV; kb += REMAP_PF) block(std::true_type{}, emit_tag, kb, std::true_type{}, FusedTag{});
   };
 
   // ---- whole sweeps, `slots` tracers at a time
@@ -1445,8 +1644,8 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   const int qsweep = qsize - left;
   for (int q0 = (tid >> 4) * NT; q0 < qsweep; q0 += slots) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) { const bool on = q0 + t < qsize; aim(t, on ? q0 + t : qsize - 1, on); }
-    prime_top();
+    for (int t = 0; t < NT; t++) { const bool on = q0 + t < qsize; aim(t, on ? q0 + t : qsize - 1, on, FusedTag{}); }
+    prime_top(FusedTag{});
     bases(0);
     nxt = fetch(std::false_type{}, 0, 0);   // the first level's operands
     if (mn_out) column(std::true_type{});
@@ -1465,7 +1664,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
       const bool act = g < ntr * NSEG, warm = g < nwarm;
       const int tr = warm ? g / (NSEG - 1) : g - nwarm, kb0 = warm ? (g - tr * (NSEG - 1) + 1) * REMAP_PF : 0;
       if (act) {
-        aim(0, qsweep + tb + tr, true);
+        aim(0, qsweep + tb + tr, true, std::false_type{});
         if (warm) {
           // state on entry of level kb0 (the one before the segment): cells kb0-2 .. kb0+2 (cell j = col[(j-1)*16], a = m*rdpo[j+1])
           const double* c = col[0] + (size_t)(kb0 - 3) * 16;
@@ -1489,18 +1688,18 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
           colw[0] = sink + p;
           bases(kb0 - REMAP_PF);
           nxt = fetch(std::true_type{}, kb0 - REMAP_PF, REMAP_PF - 1);
-          level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{});
+          level(std::true_type{}, std::false_type{}, kb0 - REMAP_PF, REMAP_PF - 1, std::true_type{}, std::false_type{});
           colw[0] = w;
         } else {
-          prime_top();
+          prime_top(std::false_type{});
           bases(0);
           nxt = fetch(std::false_type{}, 0, 0);
         }
       }
       __syncthreads();   // (waits for the loads, too)
       if (act) {
-        if (mn_out) block(std::true_type{}, std::true_type{}, kb0, std::false_type{});
-        else block(std::true_type{}, std::false_type{}, kb0, std::false_type{});
+        if (mn_out) block(std::true_type{}, std::true_type{}, kb0, std::false_type{}, std::false_type{});
+        else block(std::true_type{}, std::false_type{}, kb0, std::false_type{}, std::false_type{});
       }
     }
   }
@@ -1508,23 +1707,35 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
 
 #pragma clang fp contract(fast)   // (the default of the rest of the file)
 
-template <int NT, bool ALG2 = false>
+template <int NT, bool ALG2 = false, bool FUSED = false>
 __global__ __launch_bounds__(REMAP_THREADS / NT, NT == 1 ? 2 : 1 /* <= 256 registers: two blocks per CU */) void k_remap(
     int qsize, double dt, double ps0, const double* __restrict__ hyai, const double* __restrict__ hybi, const double* __restrict__ dp,
     const double* __restrict__ divdp_proj, double* __restrict__ dp3d, double* __restrict__ ps_v, double* __restrict__ Q, int* __restrict__ bad,
     double* __restrict__ mn_out, double* __restrict__ mx_out, int force_generic, double* __restrict__ sink,
     const double* __restrict__ dp2 /* null: the target grid of vertical_remap (:1313-1319); else remap_Q_ppm's dp2 argument [e][k][p] */,
-    const int* __restrict__ elist /* elements of this launch (null: 0..gridDim) */,
-    double* __restrict__ rdp_g /* [e][k][p] work field: 1/dp of the next step, for the bounds emission (written and read by the same block) */) {
+    const int* __restrict__ elist /* elements of this launch (null: 0..nwork) */, int nwork,
+    double* __restrict__ rdp_g /* [e][k][p] work field: 1/dp of the next step, for the bounds emission (written and read by the same block) */,
+    RemapFuse F /* FUSED: Q is written only; its cell values are (Qdp(n0) + 2*rspheremp*DSS(F.C))/3, assembled on read */) {
   extern __shared__ __align__(16) unsigned char smem_raw[];
   RemapLds& S = *reinterpret_cast<RemapLds*>(smem_raw);
-  const int e = elist ? elist[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x, nthreads = blockDim.x;
+  // blocks are dealt round-robin to the 8 XCDs: logical block = (blockIdx % 8) * (gridDim / 8) + blockIdx / 8 gives every XCD a contiguous
+  // range of the list (the lists are in slot order: an XCD works on whole patches, so that the neighbour entries the DSS on read
+  // gathers were fetched into the same L2 by the neighbouring blocks)
+  const int lb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (lb >= nwork) return;   // (whole block, before any barrier)
+  const int e = elist ? elist[lb] : lb, tid = threadIdx.x, nthreads = blockDim.x;
   double (*const pio)[16] = S.pio();
   double* const dA = S.dA();
   double* const dB = S.dB();
   double (*const dpo)[16] = S.dsel;   // phase 1 keeps dpo (index j+1) where the column loop finds dpo(kid(k)) afterwards
   double* const rdpg = rdp_g + (size_t)e * NLEV * 16;
   if (tid == 0) S.slow = force_generic;
+  if (FUSED) {
+    // what the sweeps do not assemble on read: the extra plane of C (omega_p), and the tracers that go through segment tasks -- those
+    // are put into Q here and handled in place like in the plain kernel (their old-mass prefix below reads them after the barrier)
+    const int left = remap_left(qsize, (nthreads >> 4) * NT, NT);
+    fuse_materialize(F, e, qsize, qsize - left, qsize, true, Q, tid, nthreads);
+  }
   // ---- phase 1a: dp3d = dp - dt*divdp_proj (all threads), then one thread per column for the scans
   for (int w = tid; w < NLEV * 16; w += nthreads) {
     size_t o = (size_t)e * NLEV * 16 + w;
@@ -1633,7 +1844,14 @@ __global__ __launch_bounds__(REMAP_THREADS / NT, NT == 1 ? 2 : 1 /* <= 256 regis
   }
   __syncthreads();
   // ---- phase 2: data part
-  if (S.slow) { remap_columns_generic<ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, rdpg); return; }
+  if (S.slow) {
+    if (FUSED) {   // an element that takes the generic loop: all its tracers first (the loop's windows advance by data-dependent steps)
+      fuse_materialize(F, e, qsize, 0, qsize - remap_left(qsize, (nthreads >> 4) * NT, NT), false, Q, tid, nthreads);
+      __syncthreads();
+    }
+    remap_columns_generic<ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, rdpg);
+    return;
+  }
   {
     // dpo -> dpo(kid(k)) per new level, in place: read first, write after a barrier (a row is read by the two levels above it)
     constexpr int PER = (NLEV * 16 + REMAP_THREADS / NT - 1) / (REMAP_THREADS / NT);
@@ -1656,7 +1874,7 @@ __global__ __launch_bounds__(REMAP_THREADS / NT, NT == 1 ? 2 : 1 /* <= 256 regis
     }
     __syncthreads();
   }
-  remap_columns_fast<NT, ALG2>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink, rdpg);
+  remap_columns_fast<NT, ALG2, FUSED>(S, Q, e, qsize, tid, nthreads, mn_out, mx_out, sink, rdpg, F);
 }
 
 // ---------------------------------------------------------------------------------------------------

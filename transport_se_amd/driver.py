@@ -220,7 +220,7 @@ class PrimRun:
 
     def fetch_qdp(self, tl):
         n, q = self.mine.size, self.qsize
-        return self.hip.fetch("qdp", (2, n, q, 72, 4, 4))[tl - 1]
+        return self.hip.fetch("qdp%d" % tl, (n, q, 72, 4, 4))   # (one time level: the two are separate allocations)
 
     def close(self):
         self.hip.close()

@@ -32,10 +32,11 @@ def _vp(a):
 
 class HipMod:
     def __init__(self, elem, deriv_Dvv, hvcoord, qsize, nu_q, limiter_option=8, rsplit=3, device=-1,
-                 schedule=None, exchange=None, vert_remap_q_alg=0):
+                 schedule=None, exchange=None, vert_remap_q_alg=0, lib_path=None):
         """cuda_mod_init.  hvcoord = (hyai, hybi, ps0).  schedule = dict(send=[(peer, ptrP, lengthP)...],
-        recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr, kind) -> 0."""
-        L = _lib.lib()
+        recv=[...]) as in Schedule(1)%SendCycle/RecvCycle; exchange(sendbuf_ptr, recvbuf_ptr, nlyr, kind) -> 0.
+        lib_path: another build of the same sources (_lib.HOOKS_SO: the tests' fault injection) instead of the product library."""
+        L = _lib.lib(lib_path)
         self.L = L
         self.qsize = int(qsize)
         self.nelemd = int(elem["metdet"].shape[0])
@@ -237,6 +238,13 @@ class HipMod:
         out = np.empty((self.nelemd, self.qsize))
         self._chk(self.L.tse_element_mass(self.h, int(nt), _vp(out)))
         return out
+
+    def element_qdiag(self, nt):
+        """[nelemd][qsize] each: (mass, variance, min Q, max Q) -- the element shares of prim_diag_scalars' Qmass / Qvar integrals of time
+        level nt (prim_state_mod.F90:604-655, in the reference's order of operations) and the element extrema of Q = Qdp/dp(ps_v)"""
+        out = [np.empty((self.nelemd, self.qsize)) for _ in range(4)]
+        self._chk(self.L.tse_element_qdiag(self.h, int(nt), *[_vp(x) for x in out]))
+        return tuple(out)
 
     def get_qminmax(self):
         qmin = np.empty((self.nelemd, self.qsize, NLEV)); qmax = np.empty_like(qmin)

@@ -79,6 +79,18 @@ def settings(groups):
         for k, v in groups.get(g, {}).items():
             if k in s:
                 s[k] = v
+    # the reference's namelist templates carry placeholders (ne = NE, tstep = TIME_STEP: test/dcmip1-1/dcmip1-1.nl:7,18) that its run
+    # scripts substitute with sed before they feed the file to $EXE (test/run_ne8_tests.sh:109-115); a template fed as it is must end
+    # with a message, not with a Python traceback
+    for k, typ in (("ne", int), ("qsize", int), ("ndays", int), ("nmax", int), ("rsplit", int), ("qsplit", int), ("limiter_option", int),
+                   ("statefreq", int), ("vert_remap_q_alg", int), ("hypervis_subcycle_q", int), ("tstep", float), ("nu", float), ("nu_q", float),
+                   ("hypervis_power", float), ("hypervis_scaling", float)):
+        v = s[k]
+        if isinstance(v, bool) or not isinstance(v, (int, float)) or (typ is int and int(v) != v):
+            raise SystemExit("prim_main: ctl_nl key %s = %r is not %s (namelist templates such as test/dcmip1-1/dcmip1-1.nl carry the placeholders "
+                             "NE and TIME_STEP: substitute them first, as test/run_ne8_tests.sh:109-115 does)" % (k, v, "an integer" if typ is int else "a number"))
+    if s["ne"] <= 0 or s["qsize"] <= 0 or s["tstep"] <= 0:
+        raise SystemExit("prim_main: ne = %r, qsize = %r, tstep = %r (all three must be positive)" % (s["ne"], s["qsize"], s["tstep"]))
     if s["ndays"] and s["tstep"]:
         s["nmax"] = int(s["ndays"] * 86400 / s["tstep"])       # namelist_mod.F90:347-351
     if s["nu_q"] < 0:
@@ -99,6 +111,17 @@ def settings(groups):
         raise SystemExit("prim_main: test_case must be dcmip1-1 or dcmip1-2")
     s["test"] = 1 if tc.startswith("dcmip1-1") else 2
     return s
+
+
+def _fortran_e(x, w, d):
+    """Fortran Ew.d: 0.dddE+ee (the mantissa is below 1, unlike C's %E)"""
+    if x == 0 or not np.isfinite(x):
+        return ("%*.*E" % (w, d, x)) if not np.isfinite(x) else "%*s" % (w, "0." + "0" * d + "E+00")
+    e = int(np.floor(np.log10(abs(x)))) + 1
+    m = x / 10.0 ** e
+    if abs(round(m, d)) >= 1.0:
+        m /= 10.0; e += 1
+    return "%*s" % (w, ("%.*f" % (d, m)).replace("0.", "0.", 1) + "E%+03d" % e)
 
 
 def write_hommetime(path, timers, nranks=1):
@@ -129,6 +152,34 @@ def _local_world(world):
     return world
 
 
+WATCHDOG_CHUNK = 360   # tracer steps a rank runs at most between two host synchronisations while the watchdog is armed
+
+
+class Watchdog:
+    """re-armed on progress: kick() after every milestone; a rank that misses one for `limit` seconds ends with exit code 4"""
+
+    def __init__(self, limit, rank):
+        self.limit, self.rank, self.timer, self.what = limit, rank, None, "set-up"
+        self.kick("set-up")
+
+    def _give_up(self):
+        print("prim_main: rank %d made no progress for %g s (TSE_WATCHDOG_S) in: %s -- giving up" % (self.rank, self.limit, self.what),
+              file=sys.stderr, flush=True)
+        os._exit(4)
+
+    def kick(self, what):
+        """the previous milestone was reached; `what` is what the rank does next"""
+        self.stop()
+        self.what = what
+        if self.limit > 0:
+            import threading
+            self.timer = threading.Timer(self.limit, self._give_up); self.timer.daemon = True; self.timer.start()
+
+    def stop(self):
+        if self.timer is not None:
+            self.timer.cancel(); self.timer = None
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="prim_main")
     ap.add_argument("--gpus", type=int, default=0, help="start this many ranks (one per GPU) and feed them the namelist from stdin")
@@ -150,16 +201,10 @@ def main(argv=None):
     dist = torch = None
     exchange = os.environ.get("TSE_EXCHANGE", "rccl")
     # a rank stuck in communicator set-up or in a halo exchange whose peer died must not block the job for ever (the reference's
-    # abortmp = MPI_Abort ends every rank): exit non-zero after TSE_WATCHDOG_S seconds without a result (0 disables)
-    limit = float(os.environ.get("TSE_WATCHDOG_S", "7200"))
-    watchdog = None
-    if world > 1 and limit > 0:
-        import threading
-
-        def give_up():
-            print("prim_main: rank %d has no result after %g s (TSE_WATCHDOG_S): giving up" % (rank, limit), file=sys.stderr, flush=True)
-            os._exit(4)
-        watchdog = threading.Timer(limit, give_up); watchdog.daemon = True; watchdog.start()
+    # abortmp = MPI_Abort ends every rank): a PROGRESS watchdog -- exit non-zero when TSE_WATCHDOG_S seconds (default 1800; 0 disables)
+    # pass without this rank reaching its next milestone (set-up done, a chunk of at most WATCHDOG_CHUNK tracer steps done, the final
+    # barrier passed); it stays armed until the process group is gone
+    watchdog = Watchdog(float(os.environ.get("TSE_WATCHDOG_S", "1800")) if world > 1 else 0.0, rank)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -219,27 +264,55 @@ def main(argv=None):
     hip.synchronize()
     if world > 1:
         dist.barrier()
+    watchdog.kick("the first tracer steps")
     t0 = time.perf_counter()
     np1 = 2
     diag = (not s["disable_diagnostics"]) and s["statefreq"] > 0
     n = 0
+    # prim_run_subcycle computes diagnostics in the remap cycle that ENDS at a multiple of statefreq (prim_driver_mod.F90:765-768):
+    # prim_diag_scalars before the cycle's first step (n = 1) and after its remap (n = 2), then prim_printstate.  So the run stops once
+    # at the start of such a cycle (for the "before" integrals) and once at its end.
+    scale = 1.0 / dg.G                      # prim_state_mod.F90:176-177 (ps0 = 1e5 Pa: no mb factor)
+    before = None                           # (nstep, Qmass(:,1), Qvar(:,1)) of the diagnostics cycle under way
+
+    def qdiag(tl):
+        """(Qmass, Qvar, min Q, max Q) per tracer of time level tl on rank 0: exact sums of the element shares / extrema over all ranks"""
+        m, v, lo, hi = hip.element_qdiag(tl)
+        m, v, lo, hi = gsum(m), gsum(v), gather(lo), gather(hi)
+        return (m * scale / (4.0 * np.pi), v * scale / (4.0 * np.pi), lo.min(0), hi.max(0)) if rank == 0 else (None,) * 4
     while n < nsteps:
         # run up to the next diagnostics point (a multiple of rsplit and of statefreq) without host synchronisation
         stop = nsteps
         if diag:
             f = s["statefreq"] * s["rsplit"] // np.gcd(s["statefreq"], s["rsplit"])
-            stop = min(nsteps, (run.nstep // f + 1) * f)
+            end = (run.nstep // f + 1) * f                       # end of the next diagnostics cycle
+            if end - s["rsplit"] > run.nstep:
+                stop = min(nsteps, end - s["rsplit"])            # ... stop at its start first
+            else:
+                stop = min(nsteps, end)
+                if end <= nsteps:
+                    before = (run.nstep,) + qdiag(np1 if run.nstep else 1)[:2]   # Qdp(n0) of the cycle's first step = what the last step wrote
+        if watchdog.limit > 0:   # bounded chunks, so that "no progress" can be told from "a long run" (whole rsplit cycles)
+            stop = min(stop, n + max(s["rsplit"], WATCHDOG_CHUNK // s["rsplit"] * s["rsplit"]))
         try:
             np1 = run.run(stop - n)
         except TseError as ex:   # e.g. "negative layer thickness" (prim_advection_mod.F90:1323): the reference aborts the whole job there
             abort_all("%s (tracer step %s)" % (ex, getattr(ex, "nstep", "?")))
         n = stop
+        watchdog.kick("tracer steps %d.." % n)
         if diag and run.nstep % s["statefreq"] == 0 and run.nstep % s["rsplit"] == 0:
-            ps_v = hip.fetch("ps_v", (gid.size, 4, 4))
-            mn, mx, sm = dg.element_q_partials(run.fetch_qdp(np1), dg.hybrid_dp(run.hv.hyai, run.hv.hybi, ps_v))
-            mn, mx, tot = gather(mn), gather(mx), gsum(sm)
-            for t in range(s["qsize"] if rank == 0 else 0):
-                print("nstep=%d qv(%d)= %23.15E %23.15E %23.15E" % (run.nstep, t + 1, mn[:, t].min(), mx[:, t].max(), tot[t]))
+            m2, v2, qlo, qhi = qdiag(np1)   # (formed on the device: no copy of the tracer field to the host)
+            if rank == 0:
+                # prim_printstate (prim_state_mod.F90:341-347,376-385): format 100 = (A10,3(E23.15)); qvsum = global_integral(sum_k Q*dp)*scale
+                print(" nstep= %d" % run.nstep)
+                for t in range(s["qsize"]):
+                    print("%-10s%s" % ("qv= ", "".join(_fortran_e(x, 23, 15) for x in (qlo[t], qhi[t], m2[t]))))
+                if before is not None and before[0] == run.nstep - s["rsplit"]:
+                    for t in range(s["qsize"]):   # '(a,i1,a,E22.14,a,2E15.7)': i1 overflows to '*' beyond tracer 9, as in the reference
+                        print("Q%s,Q diss, dQ^2/dt:%s kg/m^2%s%s" % (str(t + 1) if t < 9 else "*", _fortran_e(m2[t], 22, 14),
+                                                                    _fortran_e((m2[t] - before[1][t]) / s["tstep"], 15, 7),
+                                                                    _fortran_e((v2[t] - before[2][t]) / s["tstep"], 15, 7)))
+            before = None
     hip.synchronize()
     wall = time.perf_counter() - t0
     groups = {k: hip.kernel_time(k)[0] / 1e3 for k in ("advance", "dss", "lap", "minmax", "level", "remap", "dcmip")}
@@ -269,11 +342,11 @@ def main(argv=None):
             print("Q%d mass: %22.14E -> %22.14E (relative change %10.3e)" % (t + 1, m0[t], m1[t], (m1[t] - m0[t]) / max(abs(m0[t]), 1e-300)))
         print("prim_run wall %.3f s: %.4e tracer-DOF-steps/s on %d rank(s)" % (float(stack[:, 0].max()), nelem * 16 * 72 * s["qsize"] * nsteps / float(stack[:, 0].max()), world))
     run.close()
-    if watchdog:
-        watchdog.cancel()
     if world > 1:
+        watchdog.kick("the final barrier")   # (still armed: a peer that died leaves this rank in the barrier)
         dist.barrier()
         dist.destroy_process_group()
+    watchdog.stop()
     return 0
 
 
