@@ -20,6 +20,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "tests", "fortran_dropin", "_build", "hip_harness")
 MPIEXEC = "/opt/conda/bin/mpiexec"
+from conftest import record_margin  # noqa: E402
+# Tolerance against the reference's own output: TOL_STEP = 5e-13 of the field maximum per tracer step (test_gpu_parity.py: reordered
+# 16-point sums, FMA contraction, reciprocal multiplies) times the number of steps the error has accumulated over, + one step's worth
+# for the remap (a relative 1e-16 per level through the folded PPM coefficients).  gpurun_out/test_margins.jsonl records what each run
+# measured (1e-14 ... 2e-13).
+TOL_STEP = 5e-13
+TOL_DROPIN = {"qdp_step1": 1 * TOL_STEP, "qdp_step3": 4 * TOL_STEP, "qdp_step6": 8 * TOL_STEP}
 
 
 def _env(whole_step):
@@ -43,7 +50,8 @@ def test_reference_hooks_drive_the_hip_library(gold, whole_step):
     for tag, key in (("000001", "qdp_step1"), ("000003", "qdp_step3"), ("000006", "qdp_step6")):
         st = po.read_state(os.path.join(out, "state_%s_r0000.bin" % tag))
         err = np.abs(st["qdp"] - g[key]).max() / np.abs(g[key]).max()
-        assert err < 5e-12, (tag, err)
+        record_margin("fortran_dropin[%s] %s" % ("whole_step" if whole_step else "per_stage", key), err, TOL_DROPIN[key])
+        assert err < TOL_DROPIN[key], (tag, err)
     s3 = po.read_state(os.path.join(out, "state_000003_r0000.bin"))
     assert np.abs(s3["dp3d"] - g["dp3d_step3"]).max() / np.abs(g["dp3d_step3"]).max() < 1e-13
     assert np.abs(s3["ps_v"] - g["ps_v_step3"]).max() / 1e5 < 1e-13
@@ -72,7 +80,8 @@ def test_reference_hooks_multirank_mpi_exchange(gold, nranks, whole_step):
         q[st["gid"] - 1] = sd["qdp"]; seen += st["gid"].size
     assert seen == q.shape[0]
     err = np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max()
-    assert err < 5e-12, err
+    record_margin("fortran_dropin[%d ranks, %s] qdp_step6" % (nranks, "whole_step" if whole_step else "per_stage"), err, TOL_DROPIN["qdp_step6"])
+    assert err < TOL_DROPIN["qdp_step6"], err
 
 
 @pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(MPIEXEC)), reason="Fortran drop-in harness not built")
@@ -94,4 +103,4 @@ def test_rccl_mode_falls_back_to_the_mpi_exchange_when_the_communicator_cannot_b
     for r in range(2):
         st = po.read_static(os.path.join(out, "static_000000_r%04d.bin" % r))
         q[st["gid"] - 1] = po.read_state(os.path.join(out, "state_000006_r%04d.bin" % r))["qdp"]
-    assert np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max() < 5e-12
+    assert np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max() < TOL_DROPIN["qdp_step6"]

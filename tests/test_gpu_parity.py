@@ -16,6 +16,11 @@ from gpu_common import elem_from_oracle, make_hip, relerr, sync_inputs_from_orac
 
 pytestmark = pytest.mark.gpu
 TOL_STEP = 5e-13
+# test_limiter_edge_cases_through_the_step, per tracer: [0] noisy 0/1 and [3] spikes drive the limiter through many iterations in
+# which the 16-point mass sums (a tree here, a serial loop in the reference) are DIFFERENCES of nearly equal masses: the redistributed
+# increment addmass / weightssum carries the cancellation's relative error.  One step; the bound is 4 steps' worth for those two and
+# one step's worth for the smooth ones (what each run measured: gpurun_out/test_margins.jsonl).
+LIMITER_TOL = [4 * TOL_STEP, TOL_STEP, TOL_STEP, 4 * TOL_STEP, TOL_STEP]
 
 
 @pytest.fixture(scope="module")
@@ -314,8 +319,11 @@ def test_limiter_edge_cases_through_the_step(ctx5):
     o.advec_tracers_remap_rk2(dt, 0)
     hip.advec_tracers_remap_rk2(dt, 1, 2)
     hip.copy_qdp_d2h(elem, 2)
+    from conftest import record_margin
     for q in range(5):
-        assert relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q]) < 20 * TOL_STEP, q
+        err = relerr(elem["Qdp"][:, 1, q], o.qdp[1][:, q])
+        record_margin("limiter_edge_cases tracer %d" % q, err, LIMITER_TOL[q])
+        assert err < LIMITER_TOL[q], q
 
 
 @pytest.mark.parametrize("qsize", [40, 200])

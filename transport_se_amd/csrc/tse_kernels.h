@@ -574,6 +574,9 @@ template <int RHS, int GIN = 0, bool DB = (GIN != 0), int PSZ = 16 /* block shap
 #ifndef TSE_ADV2_WPE
 #define TSE_ADV2_WPE 1   // A/B: minimum waves per SIMD asked of the compiler for k_advance<2,3,.,16> (3 = the 168-register tier)
 #endif
+#ifdef TSE_ADV2_NVGPR   // A/B: cap the registers of every k_advance instance of the translation unit (tse_stage3.hip holds only <2,3>)
+__attribute__((amdgpu_waves_per_eu(TSE_ADV2_NVGPR, TSE_ADV2_NVGPR)))
+#endif
 __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3 && PSZ == 16) ? TSE_ADV2_WPE : 1) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
                                                           double* __restrict__ Tout, const double* __restrict__ vn0,
@@ -584,6 +587,11 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   static_assert(GIN != 0 || PSZ == 16, "the plain kernels have no block shape");
   __shared__ PatchLds<PSZ> lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
   __shared__ BoundsLds<PSZ> bnd_;                    // (GIN == 3 only)
+#ifndef TSE_ADV2_LDSC
+#define TSE_ADV2_LDSC 0   // A/B: the level-independent per-(element, point) constants of stage 3 (rm, the Laplacian's A B C, rspheremp) in LDS instead of registers
+#endif
+  constexpr bool LDSC = TSE_ADV2_LDSC && GIN == 3;
+  __shared__ double cst_[LDSC ? 5 : 1][LDSC ? PSZ * 16 : 1];
   constexpr int BND_ENT = BoundsLds<PSZ>::ENT, LDS_ZERO = Patch<PSZ>::LDS_ZERO;
   static_assert(BND_ENT * 4 <= Patch<PSZ>::THREADS, "one 16-byte load per lane fills the bounds image");
   constexpr bool NBR = GIN == 3;                // the limiter bounds are the min/max over the element and its neighbours of qmin/qmax, formed here
@@ -620,9 +628,13 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     load4(dp + lo, dpk);
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 0) * 16 + j * 4, vs1);
     load4(vn0 + (((size_t)e * NLEV + kc) * 2 + 1) * 16 + j * 4, vs2);
-    if (mkdiv) {
+    // Whole-step path: stage 1 forms divdp for its slab and stores it (derived%divdp is an output of the step); stage 3 (GIN == 3) forms
+    // it again from the vn0 it holds for Vstar anyway instead of reading the field back -- the same routine on the same inputs, the same
+    // bits, 0.8 GB less to read at ne120.  (Stage 2 keeps the load: the divergence in its prologue costs k_advance<1,1> its third wave,
+    // 164 -> 174 registers.)
+    if (mkdiv || GIN == 3) {
       divergence_sphere_row(D, g, vs1, vs2, t1);
-      if (k < NLEV) store4(GA.divdp_out + lo, t1);
+      if (mkdiv && k < NLEV) store4(GA.divdp_out + lo, t1);
     } else load4(divdp + lo, t1);
     if (GIN && GA.var_out && RHS == 1) {   // divdp_proj = what was just assembled (the array is being written by this launch)
 #pragma unroll
@@ -654,6 +666,15 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     if (RHS == 2) make_lap_geo(L, g);
   }
+  const int cidx = LDSC ? (int)((threadIdx.x >> 4) * 16 + j * 4) : 0;
+  if (LDSC && ((threadIdx.x >> 2) & (CL - 1)) == 0) {   // (read behind the first tracer's barrier)
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cst_[0][cidx + i] = rm[i]; cst_[1][cidx + i] = L.A[i]; cst_[2][cidx + i] = L.B[i]; cst_[3][cidx + i] = L.C[i]; cst_[4][cidx + i] = RG.rs[i]; }
+  }
+  auto ldsc4 = [&](int cI, double v[4]) __attribute__((always_inline)) {
+    const double2 a = *reinterpret_cast<const double2*>(&cst_[cI][cidx]), b = *reinterpret_cast<const double2*>(&cst_[cI][cidx + 2]);
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  };
   // NBR: per tracer the block loads the bounds of its patch's elements and of the element ring (lane = 16 bytes: entry, min|max,
   // level pair) into LDS with the tracer's other loads; after the barrier a lane reads its element's and its 8 neighbours' values
   unsigned bsrc = 0, bdst = 0, bnb[3] = {0, 0, 0};
@@ -738,8 +759,15 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     __builtin_amdgcn_sched_barrier(0);
     if (GIN) {
       lds_barrier();
+      if (LDSC) {
+        RowGather Rt = RG;
+        ldsc4(4, Rt.rs);
+        gather_sum(Rt, lds_[0], q & 1, j, own, qn);
+        gather_sum(Rt, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
+      } else {
       gather_sum(RG, lds_[0], q & 1, j, own, qn);
       if (GIN == 3) gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
+      }
     }
     if (NBR) {   // viscosity_mod.F90:429-432 on the element bounds k_lap1 left in qmin/qmax
       const char* b = reinterpret_cast<const char*>(&bnd_.v[q & 1][0][0][0]);
@@ -753,6 +781,13 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
+      if (LDSC) {
+        LapGeo Lt;
+        ldsc4(1, Lt.A); ldsc4(2, Lt.B); ldsc4(3, Lt.C);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { Lt.dcol[i] = L.dcol[i]; Lt.drow[i] = L.drow[i]; }
+        laplace_lean_row(D, Lt, ls, bih);
+      } else
       laplace_lean_row(D, L, ls, bih);
 #pragma unroll
       for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
@@ -782,8 +817,14 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
       for (int i = 0; i < 4; i++) dy[i] = ((dcol[0] * r0[i] + dcol[1] * r1[i]) + dcol[2] * r2[i]) + dcol[3] * r3[i];
     }
 #endif
+    double rmv[4];
+    if (LDSC) ldsc4(0, rmv);
+    else {
 #pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
+      for (int i = 0; i < 4; i++) rmv[i] = rm[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = qn[i] - rmv[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
     bool changed = false;
     if (RHS == 1) {
       double q0 = qn[0] * rdpk[0], q1 = qn[1] * rdpk[1], q2 = qn[2] * rdpk[2], q3 = qn[3] * rdpk[3];
