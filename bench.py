@@ -226,6 +226,17 @@ def main():
     from transport_se_amd.driver import PrimRun
     run = PrimRun(a.ne, a.qsize, test_case=1, rank=rank, world=world, device=local, dist_mod=dist, torch_mod=torch, exchange=exchange)
     comm_rank, comm_world = run.hip.comm_info()
+    if world > 1:
+        # one line per rank on stderr BEFORE the first halo exchange: who talks to whom with what -- so that a run that hangs or dies in
+        # its first exchange (the one code path no 1-GPU box can execute) can be read off the driver's tail
+        nb_, ni_ = run.hip.boundary_layout(); pb_, pi_ = run.hip.patch_layout()
+        nlyr = (a.qsize + 1) * 72
+        slots = ["%d:%dcol/%.1fMB" % (int(p), int(l), int(l) * nlyr * 8 / 1e6) for (p, _, l) in run.hip.schedule["send"]]
+        v = run.hip.comm_version()
+        print("bench.py: rank %d/%d device %d: %d elements (%d on the rank boundary), %d+%d patches (first launch + interior), exchange=%s comm=(%d,%d) "
+              "send slots peer:columns/main message [%s], bounds message %d entries; RCCL runtime %s built %s (%s)"
+              % (rank, world, local, int(run.mine.size), nb_, pb_, pi_, run.exchange_kind, comm_rank, comm_world, " ".join(slots),
+                 int(sum(run.hip.minmax_send_len)), v["runtime"], v["built"], v["path"]), file=sys.stderr, flush=True)
 
     def barrier():
         run.hip.synchronize(); torch.cuda.synchronize()

@@ -47,6 +47,9 @@ program ref_harness
                                  vertical_remap, deriv
   use vertremap_mod,      only : remap_q_ppm
   use dcmip_123_mod,      only : test1_advection_deformation, test1_advection_hadley
+#if defined(TSE_HIP) && defined(_OPENMP)
+  use omp_lib,            only : omp_get_thread_num
+#endif
 #ifdef TSE_HIP
   ! built by transport_se_amd/fortran/Makefile: prim_advection_mod is the reference's file compiled with
   ! -DUSE_CUDA_FORTRAN=1, and `cuda_mod` is transport_se_amd/fortran/cuda_mod_hip.F90 (the HIP library's Fortran seam)
@@ -73,6 +76,8 @@ program ref_harness
   real(kind=real_kind) :: rs_rel
   integer :: ne_in, qsize_in, nsteps, tcase, dumpfreq, nelem_edge
   integer :: ie, j, r, ierr, n0_qdp, np1_qdp, istep, isub, nsub
+  integer :: nthr_h, ithr_h, nets_h, nete_h, n0q_h, np1q_h      ! TSE_HARNESS_THREADS: the time loop inside !$OMP PARALLEL, as prim_main.F90:143-162
+  type (hybrid_t) :: hybrid_h
   integer(kind=8) :: c0, c1, crate
   character(len=256) :: outdir, vdir
   character(len=512) :: fname
@@ -97,6 +102,11 @@ program ref_harness
   ne = ne_in;  qsize = qsize_in;  tstep = dt
   topology = "cube";  partmethod = SFCURVE;  npart = par%nprocs
   nmpi_per_node = 1;  nnodes = npart;  nthreads = 1
+  nthr_h = 1
+#if defined(TSE_HIP) && defined(_OPENMP)
+  call env_int('TSE_HARNESS_THREADS', nthr_h)    ! horizontal OpenMP threads of the rank (NThreads of ctl_nl)
+  nthreads = max(1, nthr_h)
+#endif
   nu = 0; nu_p = 0; nu_s = 0; nu_q = nu_q_in
   limiter_option = 8; hypervis_order = 2; hypervis_subcycle_q = 1
   hypervis_power = 0; hypervis_scaling = 0
@@ -202,6 +212,48 @@ program ref_harness
   nsub = nsteps / rsplit
   call system_clock(c0, crate)
   istep = 0
+#if defined(TSE_HIP) && defined(_OPENMP)
+  if (nthr_h > 1) then
+     ! The reference runs its time loop inside !$OMP PARALLEL (prim_main.F90:143-162): every thread calls prim_run_subcycle with its own
+     ! nets:nete and hybrid, and so reaches every cuda_mod entry; the seam's BARRIER / MASTER sections let the master act for 1:nelemd.
+     ! Host-side work is split by element range; the shared time level is advanced by the master between barriers.  Only the final
+     ! state is dumped (dumpfreq = 0 semantics).
+     !$OMP PARALLEL NUM_THREADS(nthr_h) DEFAULT(SHARED) PRIVATE(ithr_h, nets_h, nete_h, hybrid_h, isub, r, n0q_h, np1q_h)
+     ithr_h   = omp_get_thread_num()
+     hybrid_h = hybrid_create(par, ithr_h, nthr_h)
+     nets_h   = 1 + (nelemd*ithr_h)/nthr_h
+     nete_h   = (nelemd*(ithr_h + 1))/nthr_h
+     if (ithr_h > 0) call Prim_Advec_Init2(hybrid_h)     ! prim_init2 runs per thread in the reference (prim_main.F90:102-111): deriv(ithr)
+     do isub = 1, nsub
+        call TimeLevel_Qdp(tl, qsplit, n0q_h, np1q_h)
+        call copy_qdp_h2d(elem, n0q_h)
+        do r = 1, rsplit
+           if (r > 1) then
+              !$OMP BARRIER
+              !$OMP MASTER
+              call TimeLevel_update(tl, "leapfrog")
+              !$OMP END MASTER
+              !$OMP BARRIER
+           endif
+           call my_prim_step_range(nets_h, nete_h, hybrid_h, ithr_h)
+           !$OMP MASTER
+           istep = istep + 1
+           !$OMP END MASTER
+        enddo
+        call TimeLevel_Qdp(tl, qsplit, n0q_h, np1q_h)
+        call vertical_remap(hybrid_h, elem, hvcoord, dt*qsplit*rsplit, tl%np1, np1q_h, nets_h, nete_h)
+        call copy_qdp_d2h(elem, np1q_h)
+        !$OMP BARRIER
+        !$OMP MASTER
+        if (dumpfreq >= 0 .and. isub == nsub) call dump_state(istep, np1q_h, tl%np1)
+        call TimeLevel_update(tl, "leapfrog")
+        !$OMP END MASTER
+        !$OMP BARRIER
+     enddo
+     !$OMP END PARALLEL
+     nsub = 0     ! (the serial loop below has nothing left to do)
+  endif
+#endif
   do isub = 1, nsub
 #ifdef TSE_HIP
      call TimeLevel_Qdp(tl, qsplit, n0_qdp, np1_qdp)       ! prim_driver_mod.F90:781-784
@@ -272,17 +324,22 @@ contains
 
   ! prim_step (prim_driver_mod.F90:856-943) + prim_advance_exp (prim_advance_mod.F90:62-152), ur_weights(1)=1
   subroutine my_prim_step()
+    call my_prim_step_range(1, nelemd, hybrid, 0)
+  end subroutine my_prim_step
+  ! the same for one thread's element range e0:e1 (its hybrid, its derivative_t); the tracer call takes nets:nete as the reference's does
+  subroutine my_prim_step_range(e0, e1, hyb, ithr)
+    integer, intent(in) :: e0, e1, ithr
+    type (hybrid_t), intent(in) :: hyb
     integer :: ie, k
     character(len=8) :: whole_step_env
-    do ie = 1, nelemd
+    do ie = e0, e1
        elem(ie)%derived%eta_dot_dpdn = 0
        elem(ie)%derived%vn0 = 0
        elem(ie)%derived%omega_p = 0
        elem(ie)%derived%dp(:,:,:) = elem(ie)%state%dp3d(:,:,:,tl%n0)
     enddo
-    time = tl%nstep*dt
-    call set_fields(tl%np1, time)
-    do ie = 1, nelemd
+    call set_fields_range(tl%np1, tl%nstep*dt, e0, e1)
+    do ie = e0, e1
        do k = 1, nlev
           elem(ie)%derived%vn0(:,:,1,k) = elem(ie)%derived%vn0(:,:,1,k) + &
                1.0d0*elem(ie)%state%v(:,:,1,k,tl%n0)*elem(ie)%derived%dp(:,:,k)
@@ -300,8 +357,8 @@ contains
        return
     endif
 #endif
-    call Prim_Advec_Tracers_remap(elem, deriv(0), hvcoord, flt, hybrid, dt*qsplit, tl, 1, nelemd)
-  end subroutine my_prim_step
+    call Prim_Advec_Tracers_remap(elem, deriv(ithr), hvcoord, flt, hyb, dt*qsplit, tl, e0, e1)
+  end subroutine my_prim_step_range
 
   ! what set_dcmip_1_1_fields / set_dcmip_1_2_fields + set_element_state + set_extra_tracers do
   ! (dcmip_wrapper_mod.F90:49-243).  omega_p is set to 0: the wrapper's cache_midpoint_values reads
@@ -309,10 +366,15 @@ contains
   subroutine set_fields(nt, time)
     integer, intent(in) :: nt
     real(kind=real_kind), intent(in) :: time
+    call set_fields_range(nt, time, 1, nelemd)
+  end subroutine set_fields
+  subroutine set_fields_range(nt, time, e0, e1)
+    integer, intent(in) :: nt, e0, e1
+    real(kind=real_kind), intent(in) :: time
     real(kind=real_kind) :: T,phis,ps,u,v,w,p,z,rho,q(4),lon,lat,term
     real(kind=real_kind) :: p_i(np,np,nlevp), p_m(np,np,nlev), q_m(np,np,nlev,4)
     integer :: ie,i,j,k,qi
-    do ie = 1, nelemd
+    do ie = e0, e1
        do k = 1, nlev
           z = Hs*log(1.0d0/hvcoord%etam(k))
           p = p0*hvcoord%etam(k)
@@ -366,7 +428,7 @@ contains
           enddo
        endif
     enddo
-  end subroutine set_fields
+  end subroutine set_fields_range
 
   ! prim_init2: Qdp = Q*dp(hybrid coefficients, ps_v(n0))   (prim_driver_mod.F90:646-669)
   subroutine qdp_from_q()

@@ -21,12 +21,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HARNESS = os.path.join(ROOT, "tests", "fortran_dropin", "_build", "hip_harness")
 MPIEXEC = "/opt/conda/bin/mpiexec"
 from conftest import record_margin  # noqa: E402
-# Tolerance against the reference's own output: TOL_STEP = 5e-13 of the field maximum per tracer step (test_gpu_parity.py: reordered
-# 16-point sums, FMA contraction, reciprocal multiplies) times the number of steps the error has accumulated over, + one step's worth
-# for the remap (a relative 1e-16 per level through the folded PPM coefficients).  gpurun_out/test_margins.jsonl records what each run
-# measured (1e-14 ... 2e-13).
+# Tolerance against the reference's own output: the per-step bound TOL_STEP = 5e-13 of the field maximum of test_gpu_parity.py
+# (reordered 16-point sums, FMA contraction, reciprocal multiplies) is what a STEP may cost in the worst case; what these runs
+# measure after 1, 3 and 6 steps (+ 2 remaps) is 0.7e-14 ... 1.1e-14 (gpurun_out/test_margins.jsonl), so the
+# drop-in is held to 1e-13 throughout: 10x the measured error, a fifth of one step's allowance.  (Round 3 asserted 5e-12.)
 TOL_STEP = 5e-13
-TOL_DROPIN = {"qdp_step1": 1 * TOL_STEP, "qdp_step3": 4 * TOL_STEP, "qdp_step6": 8 * TOL_STEP}
+TOL_DROPIN = {"qdp_step1": 1e-13, "qdp_step3": 1e-13, "qdp_step6": 1e-13}
 
 
 def _env(whole_step):
@@ -104,3 +104,60 @@ def test_rccl_mode_falls_back_to_the_mpi_exchange_when_the_communicator_cannot_b
         st = po.read_static(os.path.join(out, "static_000000_r%04d.bin" % r))
         q[st["gid"] - 1] = po.read_state(os.path.join(out, "state_000006_r%04d.bin" % r))["qdp"]
     assert np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max() < TOL_DROPIN["qdp_step6"]
+
+
+HARNESS_OMP = os.path.join(ROOT, "tests", "fortran_dropin", "_build", "hip_harness_omp")
+HARNESS_Q200 = os.path.join(ROOT, "tests", "fortran_dropin", "_build", "hip_harness_q200")
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS_OMP) and os.path.exists(MPIEXEC)), reason="OpenMP drop-in harness not built")
+@pytest.mark.parametrize("nranks,nthreads,whole_step", [(1, 2, False), (1, 3, True), (2, 2, False)])
+def test_reference_hooks_called_by_every_openmp_thread(gold, nranks, nthreads, whole_step):
+    """The reference's time loop runs inside !$OMP PARALLEL (prim_main.F90:143-162): every horizontal thread calls
+    Prim_Advec_Tracers_remap / vertical_remap with its own nets:nete and so reaches every cuda_mod entry, where the CUDA seam does
+    BARRIER / MASTER / BARRIER and lets the master act for 1:nelemd (cuda_mod.F90:6-8,211-212,408-409,549-550).  Same here:
+    hip_harness_omp = cuda_mod_hip.F90, the reference's prim_advection_mod.F90 (-DUSE_CUDA_FORTRAN=1) and the harness built with
+    -fopenmp, the time loop inside a parallel region of TSE_HARNESS_THREADS threads with the elements split between them.  The
+    output must be the single-threaded reference's."""
+    g = gold("ref_ne2_dcmip11.npz")
+    cfg = json.loads(str(g["config"]))
+    out = tempfile.mkdtemp(prefix="tse_f90omp_")
+    stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (cfg["ne"], cfg["qsize"], cfg["nsteps"], cfg["tstep"], cfg["nu_q"], cfg["test"],
+                                                 out, os.path.join(ROOT, "transport_se_amd", "data", "vcoord"))
+    res = subprocess.run([MPIEXEC, "-n", str(nranks), HARNESS_OMP], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                         env=dict(_env(whole_step), TSE_HARNESS_THREADS=str(nthreads), OMP_NUM_THREADS=str(nthreads)))
+    log = res.stdout.decode()
+    assert "ref_harness done" in log, log[-3000:]
+    q = np.empty_like(g["qdp_step6"])
+    for r in range(nranks):
+        st = po.read_static(os.path.join(out, "static_000000_r%04d.bin" % r))
+        q[st["gid"] - 1] = po.read_state(os.path.join(out, "state_000006_r%04d.bin" % r))["qdp"]
+    err = np.abs(q - g["qdp_step6"]).max() / np.abs(g["qdp_step6"]).max()
+    record_margin("fortran_dropin_omp[%d ranks x %d threads] qdp_step6" % (nranks, nthreads), err, TOL_DROPIN["qdp_step6"])
+    assert err < TOL_DROPIN["qdp_step6"], err
+
+
+@pytest.mark.skipif(not (os.path.exists(HARNESS_Q200) and os.path.exists(MPIEXEC)), reason="QSIZE_D=200 drop-in harness not built")
+def test_reference_hooks_with_200_tracers():
+    """BASELINE configs[4] (qsize = 200) through the FORTRAN seam: the reference makes the tracer extent of element_t a compile-time
+    constant (QSIZE_D, dimensions_mod.F90:12-16), so its modules and the harness are built a second time with -DQSIZE_D=200
+    (tests/fortran_dropin/Makefile).  ne8, one rsplit cycle of the reference's own hooks on the GPU against the C oracle on the same
+    analytic inputs, every tracer."""
+    ne, q, dt, nu_q = 8, 200, 400.0, 6e16
+    out = tempfile.mkdtemp(prefix="tse_f90q200_")
+    stdin = "%d %d %d %r %r %d 0\n'%s'\n'%s'\n" % (ne, q, 3, dt, nu_q, 1, out, os.path.join(ROOT, "transport_se_amd", "data", "vcoord"))
+    cmd = "ulimit -s unlimited 2>/dev/null || ulimit -s $(ulimit -H -s); exec %s -n 1 %s" % (MPIEXEC, HARNESS_Q200)   # (the reference keeps per-tracer work arrays on the stack)
+    res = subprocess.run(["bash", "-c", cmd], input=stdin.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900, env=_env(False))
+    log = res.stdout.decode()
+    assert "ref_harness done" in log, log[-3000:]
+    got = po.read_state(os.path.join(out, "state_000003_r0000.bin"))["qdp"]
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    o = po.Oracle(ne, q, nu_q=nu_q, threads=threads)
+    o.dcmip_init(1)
+    done, _ = o.prim_run(1, dt, 1)
+    assert done == 3 and got.shape == o.qdp[1].shape, (done, got.shape, o.qdp[1].shape)
+    scale = np.abs(o.qdp[1]).reshape(o.nelem, q, -1).max(2).max(0)
+    err = (np.abs(got - o.qdp[1]).reshape(o.nelem, q, -1).max(2).max(0) / scale).max()
+    record_margin("fortran_dropin_q200 qdp_step3", err, TOL_DROPIN["qdp_step3"])
+    assert err < TOL_DROPIN["qdp_step3"], err
+    o.close()

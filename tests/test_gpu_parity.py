@@ -16,11 +16,11 @@ from gpu_common import elem_from_oracle, make_hip, relerr, sync_inputs_from_orac
 
 pytestmark = pytest.mark.gpu
 TOL_STEP = 5e-13
-# test_limiter_edge_cases_through_the_step, per tracer: [0] noisy 0/1 and [3] spikes drive the limiter through many iterations in
-# which the 16-point mass sums (a tree here, a serial loop in the reference) are DIFFERENCES of nearly equal masses: the redistributed
-# increment addmass / weightssum carries the cancellation's relative error.  One step; the bound is 4 steps' worth for those two and
-# one step's worth for the smooth ones (what each run measured: gpurun_out/test_margins.jsonl).
-LIMITER_TOL = [4 * TOL_STEP, TOL_STEP, TOL_STEP, 4 * TOL_STEP, TOL_STEP]
+# test_limiter_edge_cases_through_the_step (one step; tracers: noisy 0/1, uniform, random, spikes, smooth): round 3 asserted
+# 20 * TOL_STEP here without saying why.  Measured (gpurun_out/test_margins.jsonl): 3e-16 ... 8e-16 of the
+# field maximum for all five -- the limiter's tree sums against the reference's serial sums cost nothing visible even where it
+# iterates most -- so the edge cases are held to 1e-13 (a fifth of one step's allowance, > 100x the measured error).
+LIMITER_TOL = [1e-13] * 5
 
 
 @pytest.fixture(scope="module")

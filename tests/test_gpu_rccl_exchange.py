@@ -232,3 +232,59 @@ def test_rank_rehearsal_tool_runs_one_rank_of_a_partition_in_loopback():
     assert d["world"] == 4 and d["rank"] == 1 and d["elements"] == 96 and 0 < d["boundary_elements"] < 96
     assert d["neighbour_ranks"] >= 1 and d["send_columns"] > 0 and d["ms_per_step"] > 0
     assert all(d["kernel_ms_per_step_timing_mode"][k] > 0 for k in ("advance0", "advance1", "advance2", "lap", "dss", "remap"))
+
+
+def _rank_share_loopback(ne, qsize, world, rank, strips, cycles=1):
+    """rank `rank` of the `world`-rank partition alone on the GPU, every neighbour slot pointed at rank 0 of a ONE-rank RCCL communicator
+    (tools/rank_rehearsal.py): the real split launches, pack / ncclSend / ncclRecv / unpack on the communication stream, prefetched
+    bounds exchange -- with the rank-boundary patch tiling selected by TSE_BOUNDARY_STRIPS.  Returns (Qdp bits of both time levels
+    as int64 tensors, (boundary patches, interior patches))."""
+    import torch
+    from transport_se_amd import cube_mesh as cm
+    from transport_se_amd.driver import NU_Q, TSTEP, partition
+    from transport_se_amd.hip_mod import HipMod
+    from transport_se_amd.hybvcoord import HvCoord
+    hv = HvCoord()
+    topo = cm.topology(ne); geo = cm.geometry(ne, topo)
+    d = cm.edge_descriptors(topo, partition(ne, world), rank)
+    mine = d["elems"]
+    sched = dict(send=[(0, p, l) for (_, p, l) in d["send"]], recv=[(0, p, l) for (_, p, l) in d["recv"]])
+    elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine], spheremp=geo["spheremp"][mine],
+                rspheremp=geo["rspheremp"][mine], putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
+    os.environ["TSE_BOUNDARY_STRIPS"] = "1" if strips else "0"     # (read by tse_init)
+    try:
+        h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), qsize, NU_Q[ne], device=0, schedule=sched)
+    finally:
+        os.environ.pop("TSE_BOUNDARY_STRIPS", None)
+    h.comm_init(HipMod.comm_unique_id(), 0, 1)
+    assert h.comm_info() == (0, 1)
+    h.dcmip_init(1, geo["lat"][mine], geo["lon"][mine], hv.hyam, hv.hybm)
+    h.dcmip_set_initial()
+    assert h.prim_run_subcycle(TSTEP[ne], cycles, 0) == 3 * cycles
+    h.synchronize()
+    out = []
+    for tl in (1, 2):
+        ptr, _ = h.device_ptr("qdp%d" % tl)
+        iface = {"shape": (int(mine.size) * qsize * 72 * 16,), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        out.append(torch.as_tensor(type("DevArr", (), {"__cuda_array_interface__": iface})(), device="cuda:0").clone())
+    layout = h.patch_layout()
+    h.close()
+    torch.cuda.empty_cache()
+    return out, layout
+
+
+def test_boundary_bands_under_rccl_split_launches_leave_the_bits_of_the_regular_tiling():
+    """First-contact rehearsal for the 8-GPU run (BASELINE configs[3]) on the one GPU: rank 3 of the 8-rank partition of ne120 with 35
+    tracers -- the per-rank shape of the headline multi-GPU configuration -- through the in-library RCCL exchange (c->comm set: every
+    stage launched boundary-first, pack -> ncclSend/ncclRecv -> unpack on the communication stream under the interior launch, the next
+    step's bounds exchange prefetched under the final DSS / the remap) once with the regular patch tiling and once with
+    TSE_BOUNDARY_STRIPS=1 (rank-boundary elements in two-deep bands of their own: other patches, other launch split, other halo-ring
+    tables).  The tiling is pure scheduling: the bits must not move.  (Loopback halo: the fields are not physical at the rank
+    boundary, the comparison is between the two tilings.)"""
+    import torch
+    a, la = _rank_share_loopback(120, 35, 8, 3, strips=False)
+    b, lb = _rank_share_loopback(120, 35, 8, 3, strips=True)
+    assert la != lb and lb[0] < la[0], (la, lb)                     # the bands do shrink the first launch
+    for x, y, tl in zip(a, b, (1, 2)):
+        assert torch.equal(x, y), "time level %d: %d values differ between the two tilings" % (tl, int((x != y).sum()))
+    assert int((a[0] != a[1]).sum()) > 0

@@ -875,13 +875,31 @@ int tse_comm_precheck(tse_ctx* c, int rank, int nranks) {
   int rt = 0;
   NCCLCHK(ncclGetVersion(&rt));
   // The library was compiled against rccl.h NCCL_MAJOR.NCCL_MINOR.NCCL_PATCH; the process runs whichever librccl.so.1 was loaded
-  // first (under Python: the copy bundled with torch, see _lib.py -- one RCCL per process).  The seven entry points used here
-  // (ncclGetUniqueId, ncclCommInitRank, ncclGroupStart/End, ncclSend, ncclRecv, ncclCommAbort/Destroy) have kept their
-  // signatures through all of 2.x, so a different minor is accepted and REPORTED (tse_comm_version); another major, or a
-  // runtime older than point-to-point send/recv (2.7), is refused.
+  // first (under Python: the copy bundled with torch, which ships no rccl.h to build against -- see _lib.py: one RCCL per process).
+  // What is used of RCCL is eleven entry points (ncclGetVersion, ncclGetErrorString, ncclGetUniqueId, ncclCommInitRank,
+  // ncclCommUserRank, ncclCommCount, ncclGroupStart/End, ncclSend, ncclRecv, ncclCommAbort/Destroy), ncclDouble and the 128-byte
+  // ncclUniqueId: unchanged through all of 2.x, and every one of them is EXECUTED against the runtime of the process by the loopback
+  // tests (tests/test_gpu_rccl_exchange.py: RCCL 2.26.6 from torch under headers of 2.27.7).  Policy:
+  //   * another major, or a runtime older than point-to-point send/recv (2.7): refused;
+  //   * a runtime OLDER than the headers (the Python case): accepted, and said once on stderr with both versions and the path --
+  //     refusing it would silently turn every multi-GPU run under Python into a host-staged one; TSE_RCCL_STRICT=1 refuses it
+  //     (a host that wants header == runtime, e.g. the Fortran seam linking /opt/rocm/lib/librccl.so, gets exactly that);
+  //   * a runtime newer than the headers: accepted silently (RCCL keeps old entry points).
   if (rt / 10000 != NCCL_MAJOR || rt < 20700)
     return fail("tse_comm_precheck: RCCL runtime %d.%d.%d (%s) cannot serve a library built with the headers of %d.%d.%d", rt / 10000, rt / 100 % 100,
                 rt % 100, rccl_path(), NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+  if (rt < NCCL_VERSION_CODE) {
+    const char* strict = getenv("TSE_RCCL_STRICT");
+    if (strict && atoi(strict))
+      return fail("tse_comm_precheck: RCCL runtime %d.%d.%d (%s) is older than the headers the library was built with (%d.%d.%d) and TSE_RCCL_STRICT is set",
+                  rt / 10000, rt / 100 % 100, rt % 100, rccl_path(), NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+    static bool said = false;
+    if (!said && rank == 0) {
+      fprintf(stderr, "transport_se_hip: note: RCCL runtime %d.%d.%d (%s) is older than the build headers %d.%d.%d; the entry points used are common to "
+                      "both (TSE_RCCL_STRICT=1 refuses this)\n", rt / 10000, rt / 100 % 100, rt % 100, rccl_path(), NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+      said = true;
+    }
+  }
   return 0;
 }
 int tse_comm_init(tse_ctx* c, const void* id_in, int rank, int nranks) {

@@ -446,6 +446,23 @@ __device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds<PSZ>
 // all LDS writes of the workgroup have landed; the loads of the next tracer stay in flight (no vmcnt wait)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
 
+// The tracer loop of the double-buffered kernels: tracer 0, then PAIRS (results alternate between the register sets A and B; a step
+// issues the stores of the tracer before it).  The compiler emits one copy of the step body per call site and decides FMA contraction
+// per copy, so a tracer's last bits depend on WHICH copy computed it.  With exactly three copies in fixed roles -- tracer 0, the first
+// and the second step of a pair -- tracer i is computed by the same copy whatever qsize is: tracers 1-4 of a 35-tracer run are bit
+// for bit the 4-tracer run (tests/test_gpu_baseline_configs.py).  An even tracer count therefore ends with a SURPLUS second step that
+// repeats the last tracer (it issues that tracer's stores; its own result is dropped) instead of a fourth copy of the body -- the
+// form before round 4, which gave the last tracer of an even count other last bits than the same tracer inside a longer run.
+#define TSE_TRACER_PAIRS(step, put, qsize, A, B)                          \
+  do {                                                                    \
+    step(0, nullptr, 0, A);                                               \
+    for (int q_ = 1; q_ < (qsize); q_ += 2) {                             \
+      step(q_, &A, q_ - 1, B);                                            \
+      step(q_ + 1 < (qsize) ? q_ + 1 : q_, &B, q_, A);                    \
+    }                                                                     \
+    if ((qsize) & 1) put(A, (qsize) - 1);                                 \
+  } while (0)
+
 // Element bounds out of a patch kernel: staged in LDS over 4 consecutive tracers and written as whole 128-byte lines (the layout keeps
 // the 4 levels of 4 consecutive tracers of an (element, chunk) in one aligned line: mm_idx).  One 8-byte store per (element, level,
 // tracer) -- what these kernels did before -- leaves every line to be filled by four tracers at four different times, and the memory
@@ -734,7 +751,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   fetch(0);
   // Memory schedule with DSS on read: wait for this tracer's own/ring loads -> publish them in LDS -> issue the previous
   // tracer's stores and the next tracer's loads -> workgroup barrier -> neighbour values from LDS -> compute.
-  auto step = [&](int q, const Out* prev, Out& cur) {
+  auto step = [&](int q, const Out* prev, int qprev, Out& cur) {
     double qn[4], ls[4] = {0, 0, 0, 0}, own[4], own2[4], minp = minx, maxp = maxx;
     if (GIN) gather_publish(RG, lds_[0], q & 1, kc, graw, own);
     if (GIN == 3) gather_publish(RG, lds_[GIN == 3 ? 1 : 0], q & 1, kc, graw2, own2);
@@ -754,7 +771,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     asm volatile("" : "+v"(minp), "+v"(maxp) : : "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (prev) put(*prev, q - 1);
+    if (prev) put(*prev, qprev);
     fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
     if (GIN) {
@@ -846,13 +863,9 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   };
   Out A, B;
   if (DB) {
-    step(0, nullptr, A);
-    int q = 1;
-    for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
-    if (q < qsize) { step(q, &A, B); put(B, q); }
-    else put(A, q - 1);
-  } else {   // plenty of waves (4 per SIMD): store at the end of the step, 12 registers less
-    for (int q = 0; q < qsize; q++) { step(q, nullptr, A); put(A, q); }
+    TSE_TRACER_PAIRS(step, put, qsize, A, B);
+  } else {   // plenty of waves (4 per SIMD): store at the end of the step, 12 registers less (one copy of the body)
+    for (int q = 0; q < qsize; q++) { step(q, nullptr, 0, A); put(A, q); }
   }
 }
 
@@ -929,11 +942,11 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
     store_row_pair(Bout + (size_t)q * GA.S.tps, RS, kc, k < NLEV, o.l);
   };
   stage_init(stg_);   // (ordered before its first use by the first tracer's barrier)
-  auto step = [&](int q, const Out* prev, Out& cur) {
+  auto step = [&](int q, const Out* prev, int qprev, Out& cur) {
     double x[4], own[4];
     gather_publish(RG, lds_, q & 1, kc, graw, own);
     __builtin_amdgcn_sched_barrier(0);
-    if (prev) put(*prev, q - 1);
+    if (prev) put(*prev, qprev);
     gather_issue(RG, GA, Qn0, q + 1 < qsize ? q + 1 : q, graw);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
@@ -947,11 +960,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
     laplace_lean_row(D, L, x, cur.l);
   };
   Out A, B;
-  step(0, nullptr, A);
-  int q = 1;
-  for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
-  if (q < qsize) { step(q, &A, B); put(B, q); }
-  else put(A, q - 1);
+  TSE_TRACER_PAIRS(step, put, qsize, A, B);
   lds_barrier();
   flush_bounds(stg_, (qsize - 1) >> 2, GA.pslots, pid.patch, kc / CL, qsize, qmin, qmax);
 }
@@ -1021,7 +1030,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
   if (emit) stage_init(stg_);
   // wait for this tracer's loads -> publish in LDS -> issue the PREVIOUS tracer's stores and the NEXT tracer's loads ->
   // workgroup barrier -> neighbour values from LDS -> sum (results alternate between two register sets, see k_lap1)
-  auto step = [&](int q, const Out* prev, Out& cur) {
+  auto step = [&](int q, const Out* prev, int qprev, Out& cur) {
     double own[4], qa[4], x[4];
     gather_publish(RG, lds_, q & 1, kc, graw, own);
     if (MODE == 1) {
@@ -1030,7 +1039,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
       asm volatile("" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]) : : "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (prev) put(*prev, q - 1);
+    if (prev) put(*prev, qprev);
     fetch(q + 1 < qsize ? q + 1 : q);   // branch-free: the last step re-reads its own tracer
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
@@ -1054,11 +1063,7 @@ __global__ __launch_bounds__(Patch<PSZ>::THREADS) void k_dss_patch(int qsize, co
   }
   fetch(0);
   Out A, B;
-  step(0, nullptr, A);
-  int q = 1;
-  for (; q + 1 < qsize; q += 2) { step(q, &A, B); step(q + 1, &B, A); }
-  if (q < qsize) { step(q, &A, B); put(B, q); }
-  else put(A, q - 1);
+  TSE_TRACER_PAIRS(step, put, qsize, A, B);
   if (emit) {
     lds_barrier();
     flush_bounds(stg_, (qsize - 1) >> 2, GA.pslots, pid.patch, kc / CL, qsize, mn_out, mx_out);
@@ -1294,7 +1299,16 @@ struct RemapFuse {
 #ifndef TSE_FUSE_DIAG
 #define TSE_FUSE_DIAG 0
 #endif
-struct FuseLane { unsigned oown, oa, ob; double rs; bool corner; };
+struct FuseLane { unsigned oown, oa, ob; double rs, cm /* 1.0 on a corner point, else 0.0 */; };
+// x / 3, correctly rounded, in three instructions: q = RN(x * RN(1/3)) is a faithful quotient, r = x - 3q is exact in an FMA, and
+// RN(q + r * RN(1/3)) is then RN(x / 3) (Markstein's theorem; 3 is not one of its exceptional divisors) -- the bits of the IEEE
+// division k_dss_patch<1> performs (`/ 3`: a dozen instructions with the range scaling our field values do not need), which the
+// bit-for-bit comparison of the two routes checks on every value of every parity test.
+__device__ __forceinline__ double div3(double x) {
+  constexpr double c = 1.0 / 3.0;
+  const double q = x * c;
+  return fma(fma(-3.0, q, x), c, q);
+}
 struct FuseRaw { double2 o[2], a[2], b[2]; double q[CL]; };
 __device__ __forceinline__ FuseLane fuse_lane(const RemapFuse& F, int e, int p) {
   FuseLane L;
@@ -1302,9 +1316,10 @@ __device__ __forceinline__ FuseLane fuse_lane(const RemapFuse& F, int e, int p) 
   const unsigned* et = F.etab + (size_t)e * 48;
   L.oown = ((unsigned)s * 16 + ppos(F.pperm[s], p)) * (CL * 8u);
   L.oa = et[p * 3] * (CL * 8u);
-  L.corner = (p == 0) | (p == 3) | (p == 12) | (p == 15);
+  const bool corner = (p == 0) | (p == 3) | (p == 12) | (p == 15);
+  L.cm = corner ? 1.0 : 0.0;
   const int pc = p == 1 ? 0 : p == 2 ? 3 : p == 13 ? 12 : p == 14 ? 15 : -1;   // the corner whose diagonal term this lane fetches
-  L.ob = (L.corner ? et[p * 3 + 1] : pc >= 0 ? et[pc * 3 + 2] : F.zero0) * (CL * 8u);
+  L.ob = (corner ? et[p * 3 + 1] : pc >= 0 ? et[pc * 3 + 2] : F.zero0) * (CL * 8u);
   L.rs = F.rspheremp[(size_t)e * 16 + p];
   return L;
 }
@@ -1336,13 +1351,12 @@ __device__ __forceinline__ void fuse_combine(const FuseRaw& r, const FuseLane& L
 #pragma unroll
   for (int i = 0; i < CL; i++) {
     const double d = dppq<0xA5>(b[i]);   // quad_perm [1,1,2,2]: lanes 0 and 3 of the quad receive what lanes 1 and 2 fetched for them
+    // "this contribution belongs to my point" as an exact 1.0 / 0.0 factor folded into FMAs, as in gather_sum: fma(1, x, t) = t + x rounds
+    // like the addition, fma(0, x, t) = t (x is some finite field value)
     double t = o[i] + a[i];
-    t = L.corner ? (t + b[i]) + d : t;
-#if TSE_FUSE_DIAG & 4   // A/B (last bits differ): no division
-    cur[i] = fma(2.0, L.rs * t, r.q[i]) * (1.0 / 3.0);
-#else
-    cur[i] = fma(2.0, L.rs * t, r.q[i]) / 3.0;   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage, rkstage = 3
-#endif
+    t = fma(L.cm, b[i], t);
+    t = fma(L.cm, d, t);
+    cur[i] = div3(fma(2.0, L.rs * t, r.q[i]));   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage, rkstage = 3
   }
 }
 // Qout[e][q][.][.] = (Qdp(n0) + 2*rspheremp*DSS(C))/3 for the tracers q0 <= q < q1 of element e, and var_out <- rspheremp*DSS(plane qsize)

@@ -10,8 +10,11 @@
 !     vertical_remap  -> call vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,nets,nete)                    (:1279-1282)
 ! land in the HIP library; the driver calls cuda_mod_init / copy_qdp_h2d / copy_qdp_d2h exactly where
 ! prim_driver_mod.F90:686-689,726-728,781-784,798-801 does.  Host code stays Fortran; elem(:) stays the host copy.
-! One MPI rank drives one GPU; all OpenMP threads must reach these calls with nets:nete covering 1:nelemd
-! (NThreads=1), as the CUDA seam's master-only sections assume (cuda_mod.F90:6-8).
+! One MPI rank drives one GPU.  Threading as in the CUDA seam (cuda_mod.F90:6-8,211-212,408-409,549-550,587-594): the entries are
+! called by ALL horizontal OpenMP threads of the rank (the time loop runs inside !$OMP PARALLEL, prim_main.F90:143-162), each with
+! its own nets:nete; every entry is  !$OMP BARRIER / !$OMP MASTER ... !$OMP END MASTER / !$OMP BARRIER  and the master thread acts for
+! elements 1:nelemd (elem(:) is the rank's whole shared array).  Outside a parallel region, or built without -fopenmp, the
+! directives are no-ops.
 module cuda_mod
   use iso_c_binding
   use kinds,          only : real_kind
@@ -189,6 +192,8 @@ contains
     character(len=16) :: xmode
     logical :: use_rccl
     character(kind=c_char), target, save :: comm_id(128)
+    !$OMP BARRIER
+    !$OMP MASTER
     ! What the device path does not implement is refused here, with the reference's own error route, instead of being silently
     ! replaced by the default behaviour: the tracer time levels assume qsplit = 1 (TimeLevel_Qdp, time_mod.F90:85-109), the
     ! hyperviscosity is the single constant-coefficient application of euler_step (prim_advection_mod.F90:796-826; no tracer
@@ -276,6 +281,8 @@ contains
        ! to a multiple of 4, transport_se_hip.h)
        allocate(x_hsend(max(1,ncs)*max(qsize*nlev + nlev, 2*((qsize+3)/4*4)*nlev)), x_hrecv(max(1,ncr)*max(qsize*nlev + nlev, 2*((qsize+3)/4*4)*nlev)))
     endif
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine cuda_mod_init
 
   ! bndry_exchangeV (bndry_mod.F90:74-124) on the packed slots: MPICH here is not GPU-aware, so the slots are staged
@@ -321,17 +328,25 @@ contains
   subroutine copy_qdp_h2d(elem, nt)
     type(element_t), intent(in), target :: elem(:)
     integer, intent(in) :: nt
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
     call check(tse_copy_qdp_h2d(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_h2d')
     call toc(1)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine copy_qdp_h2d
 
   subroutine copy_qdp_d2h(elem, nt)
     type(element_t), intent(in), target :: elem(:)
     integer, intent(in) :: nt
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
     call check(tse_copy_qdp_d2h(ctx, c_loc(elem(1)%state%Qdp), estride(elem), int(qsize_d,c_int), int(nt,c_int)), 'copy_qdp_d2h')
     call toc(2)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine copy_qdp_d2h
 
   subroutine euler_step_cuda(np1_qdp, n0_qdp, dt, elem, hvcoord, hybrid, deriv, nets, nete, DSSopt, rhs_multiplier)
@@ -344,8 +359,11 @@ contains
     integer,              intent(in)            :: nets, nete, DSSopt, rhs_multiplier
     integer(c_size_t) :: s
     type(c_ptr) :: pdiv, peta, pomg
+    ! (every thread arrives with its own nets:nete: the barrier makes the host-side writes of all of them -- elem%derived of the
+    ! tracer step -- visible before the master stages them, and the closing barrier keeps the others out of Qdp until it is back)
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
-    if (nets /= 1 .or. nete /= nelemd) call seam_abort('euler_step_cuda(hip): needs NThreads=1 (nets:nete = 1:nelemd)')
     s = estride(elem)   ! every field lives in the same fixed-size element_t, so one stride serves all
     ! The CUDA seam stages elem%derived on every call (cuda_mod.F90:535-547, 564-586).  Nothing on the host changes vn0, dp,
     ! divdp, eta_dot_dpdn or omega_p between the three euler_step calls of a tracer step (prim_advection_mod.F90:614-637), and
@@ -365,6 +383,8 @@ contains
     call check(tse_get_derived(ctx, pdiv, s, peta, s, pomg, s, c_null_ptr, 0_c_size_t, c_null_ptr, 0_c_size_t, &
                                c_null_ptr, 0_c_size_t), 'tse_get_derived')
     call toc(3)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine euler_step_cuda
 
   ! The body of Prim_Advec_Tracers_remap_rk2 (prim_advection_mod.F90:600-636: divdp = div(vn0), three euler_steps, qdp_time_avg)
@@ -379,6 +399,8 @@ contains
     real(kind=real_kind), intent(in)            :: dt
     integer,              intent(in)            :: n0_qdp, np1_qdp
     integer(c_size_t) :: s
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
     s = estride(elem)
     call check(tse_set_derived(ctx, c_loc(elem(1)%derived%vn0), s, c_loc(elem(1)%derived%dp), s, &
@@ -389,15 +411,21 @@ contains
                                c_loc(elem(1)%derived%omega_p), s, c_loc(elem(1)%derived%divdp), s, c_null_ptr, 0_c_size_t, &
                                c_null_ptr, 0_c_size_t), 'tse_get_derived')
     call toc(4)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine advec_tracers_remap_rk2_hip
 
   subroutine qdp_time_avg_cuda(elem, rkstage, n0_qdp, np1_qdp, limiter_option, nu_p, nets, nete)
     type(element_t),      intent(inout) :: elem(:)
     real(kind=real_kind), intent(in)    :: nu_p
     integer,              intent(in)    :: rkstage, n0_qdp, np1_qdp, nets, nete, limiter_option
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
     call check(tse_qdp_time_avg(ctx, int(rkstage,c_int), int(n0_qdp,c_int), int(np1_qdp,c_int)), 'qdp_time_avg_cuda')
     call toc(3)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine qdp_time_avg_cuda
 
   ! call site: vertical_remap_cuda(elem,hvcoord,dt,np1,np1_qdp,nets,nete)   (prim_advection_mod.F90:1280)
@@ -409,6 +437,8 @@ contains
     integer(c_size_t) :: s
     integer :: ie
     real(kind=real_kind), allocatable, target :: dp3d(:,:,:,:), psv(:,:,:)
+    !$OMP BARRIER
+    !$OMP MASTER
     call tic()
     s = estride(elem)
     call check(tse_set_derived(ctx, c_null_ptr, 0_c_size_t, c_loc(elem(1)%derived%dp), s, c_null_ptr, 0_c_size_t, &
@@ -425,6 +455,8 @@ contains
        elem(ie)%state%ps_v(:,:,np1)   = psv(:,:,ie)
     enddo
     call toc(5)
+    !$OMP END MASTER
+    !$OMP BARRIER
   end subroutine vertical_remap_cuda
 
 end module cuda_mod

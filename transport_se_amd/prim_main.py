@@ -260,6 +260,9 @@ def main(argv=None):
     nsteps = (s["nmax"] // s["rsplit"]) * s["rsplit"]
     say(" nmax = %d tracer steps, tstep = %g, ne = %d, qsize = %d, nu_q = %g, %d rank(s), exchange = %s"
         % (nsteps, s["tstep"], s["ne"], s["qsize"], s["nu_q"], world, run.exchange_kind))
+    if world > 1:
+        v = hip.comm_version()
+        say(" RCCL runtime %s (%s), library built with the headers of %s" % (v["runtime"], v["path"], v["built"]))
     hip.timing(True)
     hip.synchronize()
     if world > 1:
