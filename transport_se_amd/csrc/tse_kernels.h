@@ -1296,9 +1296,6 @@ struct RemapFuse {
   double* var_out;                 // omega_p <- rspheremp * DSS(plane qsize of C)  (prim_advection_mod.F90:943-957), may be null
   unsigned zero0;                  // entry of the all-zero slot
 };
-#ifndef TSE_FUSE_DIAG
-#define TSE_FUSE_DIAG 0
-#endif
 struct FuseLane { unsigned oown, oa, ob; double rs, cm /* 1.0 on a corner point, else 0.0 */; };
 // x / 3, correctly rounded, in three instructions: q = RN(x * RN(1/3)) is a faithful quotient, r = x - 3q is exact in an FMA, and
 // RN(q + r * RN(1/3)) is then RN(x / 3) (Markstein's theorem; 3 is not one of its exceptional divisors) -- the bits of the IEEE
@@ -1309,7 +1306,7 @@ __device__ __forceinline__ double div3(double x) {
   const double q = x * c;
   return fma(fma(-3.0, q, x), c, q);
 }
-struct FuseRaw { double2 o[2], a[2], b[2]; double q[CL]; };
+struct FuseRaw { double2 o[2], a[2], b[2]; };
 __device__ __forceinline__ FuseLane fuse_lane(const RemapFuse& F, int e, int p) {
   FuseLane L;
   const int s = F.slot_of[e];
@@ -1323,29 +1320,23 @@ __device__ __forceinline__ FuseLane fuse_lane(const RemapFuse& F, int e, int p) 
   L.rs = F.rspheremp[(size_t)e * 16 + p];
   return L;
 }
-// the loads of chunk kc of one tracer column: plane = &C[q][0] as bytes, q0col = &Qn0[e][q][0][p]
-__device__ __forceinline__ void fuse_issue(FuseRaw& r, const char* __restrict__ plane, unsigned cstride /* bytes per chunk */, int kc, const FuseLane& L,
-                                           const double* __restrict__ q0col) {
+// the loads of chunk kc of one tracer column: plane = &C[q][0] as bytes, q0col = &Qn0[e][q][0][p].  The Qdp(n0) values are issued
+// apart from the scratch entries: they are 4 registers a chunk against 12, so that stream is kept TSE_FUSE_QAHEAD chunks further ahead
+#ifndef TSE_FUSE_QAHEAD
+#define TSE_FUSE_QAHEAD 0   // (1, 2: measured, no gain -- profiles/r04_ab_remap_dss_on_read.txt)
+#endif
+__device__ __forceinline__ void fuse_issue(FuseRaw& r, const char* __restrict__ plane, unsigned cstride /* bytes per chunk */, int kc, const FuseLane& L) {
   const char* b = plane + (size_t)kc * cstride;
   r.o[0] = *reinterpret_cast<const double2*>(b + L.oown); r.o[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
-#if TSE_FUSE_DIAG & 1   // A/B (WRONG results): no ring traffic, same instructions
-  r.a[0] = *reinterpret_cast<const double2*>(b + L.oown);   r.a[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
-  r.b[0] = *reinterpret_cast<const double2*>(b + L.oown);   r.b[1] = *reinterpret_cast<const double2*>(b + L.oown + 16);
-#elif TSE_FUSE_DIAG & 8   // A/B (WRONG results): no neighbour loads at all
-  r.a[0] = r.a[1] = r.b[0] = r.b[1] = make_double2(0., 0.);
-#else
   r.a[0] = *reinterpret_cast<const double2*>(b + L.oa);   r.a[1] = *reinterpret_cast<const double2*>(b + L.oa + 16);
   r.b[0] = *reinterpret_cast<const double2*>(b + L.ob);   r.b[1] = *reinterpret_cast<const double2*>(b + L.ob + 16);
-#endif
+}
+__device__ __forceinline__ void fuse_issue_q(double q[CL], int kc, const double* __restrict__ q0col) {
 #pragma unroll
-#if TSE_FUSE_DIAG & 2   // A/B (WRONG results): no Qdp(n0) stream
-  for (int i = 0; i < CL; i++) r.q[i] = 1.0;
-#else
-  for (int i = 0; i < CL; i++) r.q[i] = q0col[(size_t)(kc * CL + i) * 16];
-#endif
+  for (int i = 0; i < CL; i++) q[i] = q0col[(size_t)(kc * CL + i) * 16];
 }
 // (all four lanes of a quad call it together: the hand-over of the corner's diagonal term is a DPP move)
-__device__ __forceinline__ void fuse_combine(const FuseRaw& r, const FuseLane& L, double cur[CL]) {
+__device__ __forceinline__ void fuse_combine(const FuseRaw& r, const double q[CL], const FuseLane& L, double cur[CL]) {
   const double o[CL] = {r.o[0].x, r.o[0].y, r.o[1].x, r.o[1].y}, a[CL] = {r.a[0].x, r.a[0].y, r.a[1].x, r.a[1].y},
                b[CL] = {r.b[0].x, r.b[0].y, r.b[1].x, r.b[1].y};
 #pragma unroll
@@ -1356,7 +1347,7 @@ __device__ __forceinline__ void fuse_combine(const FuseRaw& r, const FuseLane& L
     double t = o[i] + a[i];
     t = fma(L.cm, b[i], t);
     t = fma(L.cm, d, t);
-    cur[i] = div3(fma(2.0, L.rs * t, r.q[i]));   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage, rkstage = 3
+    cur[i] = div3(fma(2.0, L.rs * t, q[i]));   // (Qdp(n0) + (rkstage-1)*Qdp(np1))/rkstage, rkstage = 3
   }
 }
 // Qout[e][q][.][.] = (Qdp(n0) + 2*rspheremp*DSS(C))/3 for the tracers q0 <= q < q1 of element e, and var_out <- rspheremp*DSS(plane qsize)
@@ -1513,6 +1504,7 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   // materialized in Q beforehand (k_remap)
   FuseLane FL{};
   FuseRaw fraw;
+  double fq[TSE_FUSE_QAHEAD + 1][CL];   // Qdp(n0) of the chunk in fraw ([0]) and of the TSE_FUSE_QAHEAD chunks behind it
   double fcur[CL] = {0, 0, 0, 0};
   const char* fplane = nullptr;
   const unsigned fcstride = FUSED ? F.S.cse * (CL * 8u) : 0u;
@@ -1540,11 +1532,14 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
   // window at the top of the column: a(0) = a(1), a(-1) = a(2)
   auto prime_top = [&](auto fused_tag) __attribute__((always_inline)) {
     if constexpr (decltype(fused_tag)::value) {   // chunk 0 -> cells 1 .. 4 (the fourth waits in fcur[3]); chunk 1 on its way
-      fuse_issue(fraw, fplane, fcstride, 0, FL, col[0]);
-      fuse_combine(fraw, FL, fcur);
+      fuse_issue(fraw, fplane, fcstride, 0, FL);
+      fuse_issue_q(fq[0], 0, col[0]);
+      fuse_combine(fraw, fq[0], FL, fcur);
       mk[0] = fcur[0]; mk1[0] = fcur[1]; mk2[0] = fcur[2];
       asm volatile("" : "+v"(fcur[3]) : : "memory");   // (the values have left fraw before the next loads are issued into it)
-      fuse_issue(fraw, fplane, fcstride, 1, FL, col[0]);
+      fuse_issue(fraw, fplane, fcstride, 1, FL);
+#pragma unroll
+      for (int u = 0; u <= TSE_FUSE_QAHEAD; u++) fuse_issue_q(fq[u], 1 + u, col[0]);
     } else {
 #pragma unroll
     for (int t = 0; t < NT; t++) {
@@ -1608,10 +1603,15 @@ __device__ __forceinline__ void remap_columns_fast(const RemapLds& S, double* __
         // issued four levels ago; combine them and send for the next chunk
         const int ci = (sl + 3) & (CL - 1);
         if (ci == 0) {
-          fuse_combine(fraw, FL, fcur);
+          fuse_combine(fraw, fq[0], FL, fcur);
           asm volatile("" : "+v"(fcur[0]), "+v"(fcur[1]), "+v"(fcur[2]), "+v"(fcur[3]) : : "memory");
           const int kn = (r - 1) / CL + 1;
-          if (!TAIL || kn < NCHUNK) fuse_issue(fraw, fplane, fcstride, kn, FL, col[0]);
+          if (!TAIL || kn < NCHUNK) fuse_issue(fraw, fplane, fcstride, kn, FL);
+#pragma unroll
+          for (int u = 0; u < TSE_FUSE_QAHEAD; u++)
+#pragma unroll
+            for (int i = 0; i < CL; i++) fq[u][i] = fq[u + 1][i];   // (renamed away inside the unrolled block)
+          if (!TAIL || kn + TSE_FUSE_QAHEAD < NCHUNK) fuse_issue_q(fq[TSE_FUSE_QAHEAD], kn + TSE_FUSE_QAHEAD, col[0]);
         }
         mk3[0] = fcur[ci];
         ak3[0] = mk3[0] * c.rr;
