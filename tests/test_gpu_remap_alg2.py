@@ -36,6 +36,8 @@ def test_remap_q_ppm_alg2_single_call_vs_reference(gold, monkeypatch, generic):
     q = g["remap_Qin"][which]; dp1 = g["remap_dp1"][which]; dp2 = g["remap_dp2"][which]
     out = hip.remap_q_ppm(q, dp1, dp2)
     ref = g["remap_Qout"][which]
+    from conftest import record_margin
+    record_margin("remap_q_ppm alg 2 single call vs reference (generic=%s)" % generic, relerr(out, ref), 5e-13)
     assert relerr(out, ref) <= 5e-13, relerr(out, ref)
     np.testing.assert_allclose(out.sum(2), q.sum(2), rtol=1e-13)    # column mass
     # and it IS a different algorithm: the default context does not reproduce these outputs
