@@ -10,6 +10,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("TSE_PLACEMENT", "0")   # the experiment assigns the roles itself
+from transport_se_amd import _lib  # noqa: E402
+os.environ.setdefault("TSE_LIB", _lib.HOOKS_SO)   # the tse_debug_* entry points exist only in the -DTSE_AB_HOOKS build
 from transport_se_amd.driver import PrimRun  # noqa: E402
 import torch  # noqa: E402
 

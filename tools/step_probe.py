@@ -7,6 +7,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transport_se_amd import _lib  # noqa: E402
+os.environ.setdefault("TSE_LIB", _lib.HOOKS_SO)   # the tse_debug_* entry points exist only in the -DTSE_AB_HOOKS build
 from transport_se_amd.driver import PrimRun  # noqa: E402
 import torch  # noqa: E402
 

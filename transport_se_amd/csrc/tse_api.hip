@@ -1567,6 +1567,7 @@ static int remap_check(tse_ctx* c) {
   return 0;
 }
 int tse_vertical_remap(tse_ctx* c, double dt, int np1_qdp) {
+  c->dss_deferred_n0 = 0;   // (only tse_prim_run_subcycle defers a final DSS to its remap; a call of its that failed in between must not leave the request behind)
   if (remap_launch(c, dt, np1_qdp, false)) return 1;
   return remap_check(c);
 }
@@ -1704,6 +1705,7 @@ static int dcmip_step_launch(tse_ctx* c, int nstep, double tstep, hipStream_t st
 }
 int tse_dcmip_step_inputs(tse_ctx* c, int nstep, double tstep) { return join_inputs(c) || dcmip_step_launch(c, nstep, tstep, c->stream); }
 int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
+  c->dss_deferred_n0 = 0;
   const int nstep0 = *nstep_io;
   int nstep = nstep0;
   // The reference aborts in the first remap that meets a negative layer thickness (prim_advection_mod.F90:1323).  Here the
