@@ -23,18 +23,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_DOF_STEP = 400.0 / 3.0   # 16 2/3 mandatory fp64 field passes per tracer step
-# what the pipeline that is actually built must move: 12 tracer-field passes per step; on every rsplit-th step
-# the remap assembles the final DSS + time average on read (C, Qdp(n0) -> remapped Qdp(np1): 3 passes) instead of k_dss_patch<1>
-# (3 passes) + an in-place remap (2): 12 passes on average.  With TSE_REMAP_FUSED=0 (round 3's pipeline): 12 2/3.
+# what the pipeline that is actually built must move, in tracer-field passes per step: stage 1: 2 (Qdp(n0) -> T),
+# stage 2: 2 (T -> B), stage 3a: 1 1/4 (k_lap1 reads B and stores only the quarter of its Laplacian that other patches and ranks read),
+# stage 3b: 2 (B -> C; k_advance<2,3> forms the Laplacian of its own slots itself and reads only the halo ring of T), final DSS + time
+# average: 3 (C, Qdp(n0) -> Qdp(np1)); on every rsplit-th step the remap does that last part on read (3 passes, no k_dss_patch<1>).
+# 10 1/4 passes = 82 B per DOF-step (round 3: 12 2/3 = 101.3; with TSE_REMAP_FUSED=0: + 2/3).
 REMAP_FUSED = os.environ.get("TSE_REMAP_FUSED", "1") != "0" and os.environ.get("TSE_DSS_ON_READ", "1") != "0"
-PIPELINE_BYTES_PER_DOF_STEP = (12.0 if REMAP_FUSED else 12.0 + 2.0 / 3.0) * 8.0
+PIPELINE_BYTES_PER_DOF_STEP = (10.25 if REMAP_FUSED else 10.25 + 2.0 / 3.0) * 8.0
 BASELINE_PUBLISHED = 3.92e9            # ne120/72L/q35, 960 Edison cores (README:174), other hardware
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic bytes per DOF of ONE launch of each kernel (DESIGN.md "kernels"): tracer fields read + written, 8 B each.
 # Default path (DSS on read): advance0 = k_advance<0> (Qdp -> T), advance1 = k_advance<1,1> (T -> B), lap = k_lap1<1>
 # (B -> Laplacian in T), advance2 = k_advance<2,3> (B, T -> C), dss = k_dss_patch<1> (C, Qdp(n0) -> Qdp(np1)): 12 field passes per
 # tracer step + 2/3 for the remap = 101 B per DOF-step.
-KERNEL_BYTES_PER_DOF = {"advance0": 16.0, "advance1": 16.0, "lap": 16.0, "advance2": 24.0, "dss": 24.0, "remap": 24.0 if REMAP_FUSED else 16.0}
+KERNEL_BYTES_PER_DOF = {"advance0": 16.0, "advance1": 16.0, "lap": 10.0, "advance2": 16.0, "dss": 24.0, "remap": 24.0 if REMAP_FUSED else 16.0}
+# what round 3's accounting charged the same kernels (k_lap1 stored its whole Laplacian, k_advance<2,3> read it back as a third field):
+# kept so that roofline.frac can be compared across rounds (roofline.frac_round3_accounting)
+KERNEL_BYTES_PER_DOF_R3 = {"lap": 16.0, "advance2": 24.0}
 KERNEL_NAMES = {"advance0": "k_advance<0,0>", "advance1": "k_advance<1,1>", "advance2": "k_advance<2,3>", "lap": "k_lap1<1>",
                 "dss": "k_dss_patch<1>", "remap": "k_remap<1,0,1>" if REMAP_FUSED else "k_remap<1,0,0>"}
 if os.environ.get("TSE_DSS_ON_READ", "1") == "0":   # one DSS pass per stage: 4 dss launches (3 x 16 + 24), lap = k_lap1<0>
@@ -311,6 +316,11 @@ def main():
                          # from the committed profile of the same kernel sources (hash-checked), collected as the guide prescribes
                          "traffic_measured_in_this_run": False, "avg_ms": ms / max(n, 1), "launches": n, "kernel_timing_in_timed_region": kernel_timing,
                          "alg_bytes_per_launch": KERNEL_BYTES_PER_DOF[dom] * dof_local,
+                         # the same kernel time priced with round 3's bytes for that kernel (k_advance<2,3> then read the first Laplacian as
+                         # a third field; now it computes it: fewer bytes, more VALU work, a shorter step)
+                         "frac_round3_accounting": (KERNEL_BYTES_PER_DOF_R3.get(dom, KERNEL_BYTES_PER_DOF[dom]) * dof_local / 1e9) / (ms / max(n, 1) / 1e3) / HBM_PEAK_GBS if ms > 0 else 0.0,
+                         "dominant_kernel_note": ("k_advance<2,3> forms the first Laplacian of its own slots itself since round 4: it is bound by fp64 VALU issue "
+                                                  "(SQ counters in profiles/), not by HBM; whole_step_frac is the figure that tracks the step") if dom == "advance2" else None,
                          # whole step against SURVEY 8(d)'s 133.3 B per DOF-step (kept for continuity between rounds) ...
                          "whole_step_frac": value * ALG_BYTES_PER_DOF_STEP / (world * HBM_PEAK_GBS * 1e9),
                          # ... and against the bytes THIS pipeline must move (12 2/3 field passes = 101.3 B per DOF-step)

@@ -122,6 +122,7 @@ struct tse_ctx {
   int kshape[4] = {16, 16, 16, 16};        // block shape of k_advance<1,1>, k_lap1<1>, k_advance<2,3>, k_dss_patch (patch_shape)
   const PatchSet& set_of(int k) const { return pset[kshape[k] == 32 ? 2 : kshape[k] == 24 ? 1 : 0]; }
   unsigned long long* pperm = nullptr;   // point order inside every slot of the scratch layout
+  unsigned char* pexp = nullptr;         // [slot] lines of the slot that hold points read from outside its patch (k_lap1<1> stores only those)
   unsigned* etab = nullptr;              // [e][16][3] entry (within a chunk) of the DSS contributions of a point: the remap's DSS on read (RemapFuse)
   int dss_deferred_n0 = 0;               // != 0: the last tracer step left C pre-DSS for the remap to assemble; value = its n0_qdp (tse_prim_run_subcycle only)
   int2* send_src_s = nullptr;   // the send columns in slot space
@@ -150,7 +151,7 @@ struct tse_ctx {
   GatherArgs gargs(const PatchSet& P, const int* order_, int nwork_, const int* plist_, int npwork_, const double* var_in = nullptr, int var_in_lev = 0,
                    double* var_out = nullptr, int var_out_lev = 0) const {
     return GatherArgs{scr(), slot_of, order_, nwork_, rspheremp, P.pslots, P.pring, P.plds, plist_, npwork_, var_in, var_in_lev, var_out, var_out_lev, nullptr,
-                      P.pering, P.pnb, pperm};
+                      P.pering, P.pnb, pperm, nullptr};
   }
   int mm_m() const { return mm_qpad(qsize) * NLEV; }   // entries per element of the bounds arrays (tse_kernels.h: mm_idx)
   size_t lev() const { return (size_t)nelemd * NLEV * 16; }
@@ -592,6 +593,10 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     // its reader two lines.  The points nobody reads from outside fill what is left.
     // TSE_AB_FIXED_PERM=1: the former fixed perimeter-first order (A/B).
     std::vector<unsigned long long> pperm((size_t)c->nslots, 0x67895FEA4DCB3210ULL);
+    // lines of a slot that k_lap1<1> must store: 1 + the last line that holds a point some patch's halo ring (of any tiling in use) or a
+    // send column reads -- taken from those tables themselves below, so that it covers corner-only readers and irregular patches too;
+    // the per-slot order packs the exported edges into the first lines, so this is a quarter of the field on average
+    std::vector<unsigned char> pexp((size_t)c->nslots, 0);
     if (!(hook_env("TSE_AB_FIXED_PERM") && atoi(hook_env("TSE_AB_FIXED_PERM")))) {
       static const int edge_dir[4] = {2, 3, 0, 1};   // S, N, W, E as direction indices (west, east, south, north = 0..3)
       for (int e = 0; e < n; e++) {
@@ -653,6 +658,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
           }
         }
       }
+      for (unsigned ent : pring)   // what this tiling's halo rings read from the slots
+        if (ent < (unsigned)c->nslots * 16) pexp[ent / 16] = std::max<unsigned char>(pexp[ent / 16], (unsigned char)((ent % 16) / 4 + 1));
       // element ring and neighbour entries of every patch, for the bounds image of the stage-3 kernel (k_advance<2,3>)
       std::vector<int> pering((size_t)P.npatch * NER, 0);
       std::vector<unsigned char> pnb(nts * 8, 255);
@@ -688,7 +695,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     }
     std::vector<int2> send_s(send_src);
     for (int2& t : send_s) { t.x = slot_of[t.x]; t.y = ppos(pperm[t.x], t.y); }   // {slot, position within the slot}
-    if (upload(&c->slot_of, slot_of) || upload(&c->send_src_s, send_s) || upload(&c->pperm, pperm)) return 1;
+    for (const int2& t : send_s) pexp[t.x] = std::max<unsigned char>(pexp[t.x], (unsigned char)(t.y / 4 + 1));   // what the pack kernel reads
+    if (upload(&c->slot_of, slot_of) || upload(&c->send_src_s, send_s) || upload(&c->pperm, pperm) || upload(&c->pexp, pexp)) return 1;
     // the same contributions per ELEMENT as global entries of a chunk, for the remap that assembles the last DSS of a cycle on read
     std::vector<unsigned> etab((size_t)n * 48);
     for (size_t i = 0; i < etab.size(); i++) {
@@ -791,7 +799,7 @@ void tse_finalize(tse_ctx* c) {
   void* ptrs[] = {c->dcmip_tab, c->dvv_d, c->Dinv, c->metdet, c->rmetdet, c->spheremp, c->rspheremp, c->hyai, c->hybi, c->dp0, c->dss_tab, c->send_src,
                   c->nbr, c->mm_send_src, c->qorig[0] ? c->qorig[0] : c->qlev[0], c->qorig[0] ? c->qorig[1] : c->qlev[1], c->vn0, c->dp, c->divdp, c->divdp_proj, c->eta, c->omega_p, c->dp3d, c->ps_v,
                   c->lvl_tmp, c->eta2, c->sink, c->order, c->qmin, c->qmax, c->qmin2, c->qmax2, c->bad, c->lat, c->lon, c->zm, c->zi, c->pint, c->dph,
-                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm, c->etab, c->rl_all, c->rl_bnd, c->rl_int};
+                  c->sendbuf, c->recvbuf, c->sendbuf_mm, c->recvbuf_mm, c->ord_bnd, c->ord_int, c->slot_of, c->send_src_s, c->pperm, c->pexp, c->etab, c->rl_all, c->rl_bnd, c->rl_int};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (c->pool.empty()) { for (double* p : {c->T, c->B, c->C}) if (p) (void)hipFree(p); }
   else for (double* p : c->pool) if (p) (void)hipFree(p);
@@ -1437,8 +1445,10 @@ static int advec_dss_on_read(tse_ctx* c, double dts /* stage dt = dt/2 */, int n
           if (!w.npwork) return 0;
           with_shape(w.P->psz, [&](auto psz) {
             constexpr int Z = decltype(psz)::value;
+            GatherArgs ga = gargs(w, nullptr, 0, c->eta, NLEVP);
+            ga.pexp = c->pexp;   // only what other patches and ranks read of the first Laplacian is stored: stage 3b forms its own slots' itself
             hipLaunchKernelGGL((k_lap1<1, Z>), dim3(patch_blocks(w.npwork)), dim3(Patch<Z>::THREADS), 0, c->stream, c->nelemd, c->D, c->geo(), c->qsize, 2 * dts,
-                               (const double*)c->B, c->T, c->dp, c->divdp_proj, c->qmin, c->qmax, gargs(w, nullptr, 0, c->eta, NLEVP));
+                               (const double*)c->B, c->T, c->dp, c->divdp_proj, c->qmin, c->qmax, ga);
             return 0; });
           LAUNCH_CHECK(); return 0; },
         [&]() -> int { return pack_minmax(c, cs) || halo_exchange(c, 2 * c->mm_m(), 1, cs) || unpack_minmax(c, cs) || pack_tracers(c, cs, c->T, nq) ||

@@ -126,7 +126,23 @@ __device__ __forceinline__ void make_lap_geo(LapGeo& L, const RowGeo& g) {
     L.dcol[i] = g.dcol[i]; L.drow[i] = g.drow[i];
   }
 }
+// The first Laplacian of stage 3 is formed in TWO kernels -- k_lap1 for the values other patches and ranks read, k_advance<2,3> for
+// its own slots -- and both must give a point the SAME bits (otherwise the result would depend on where patch and rank boundaries
+// lie).  What the compiler fuses on its own is decided per inlined copy, so these routines are compiled without implicit contraction
+// and spell their fused operations out.
+// dp of a stage: dp - c * divdp_proj (c = rhs_multiplier * dt; prim_advection_mod.F90:750-761)
+__device__ __forceinline__ double dp_stage(double dp, double c, double dvp) {
+#pragma clang fp contract(off)
+  return fma(-c, dvp, dp);
+}
+// Q = Qdp * (1/dp) at the lane's 4 points
+__device__ __forceinline__ void lap_q_of(const double qdp[4], const double rdp[4], double q[4]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 4; i++) q[i] = qdp[i] * rdp[i];
+}
 __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L, const double s[4], double lap[4]) {
+#pragma clang fp contract(off)
 #ifdef TSE_NO_CONTRACTION   // A/B build: see k_advance
   for (int i = 0; i < 4; i++) lap[i] = (L.A[i] + L.B[i] + L.C[i]) * s[i];
   return;
@@ -135,19 +151,18 @@ __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L
   double w1[4], w2[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const double dx = ((D.d[i * 4] * s[0] + D.d[i * 4 + 1] * s[1]) + D.d[i * 4 + 2] * s[2]) + D.d[i * 4 + 3] * s[3];
-    const double dy = ((L.dcol[0] * quad_bcast<0>(s[i]) + L.dcol[1] * quad_bcast<1>(s[i])) + L.dcol[2] * quad_bcast<2>(s[i])) +
-                      L.dcol[3] * quad_bcast<3>(s[i]);
-    w1[i] = L.A[i] * dx + L.B[i] * dy;
-    w2[i] = L.B[i] * dx + L.C[i] * dy;
+    const double dx = fma(D.d[i * 4 + 3], s[3], fma(D.d[i * 4 + 2], s[2], fma(D.d[i * 4 + 1], s[1], D.d[i * 4] * s[0])));
+    const double dy = fma(L.dcol[3], quad_bcast<3>(s[i]), fma(L.dcol[2], quad_bcast<2>(s[i]), fma(L.dcol[1], quad_bcast<1>(s[i]), L.dcol[0] * quad_bcast<0>(s[i]))));
+    w1[i] = fma(L.B[i], dy, L.A[i] * dx);
+    w2[i] = fma(L.C[i], dy, L.B[i] * dx);
   }
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     double d = 0.0;
-    d = d - (w1[0] * D.d[0 * 4 + m] + quad_bcast<0>(w2[m]) * L.drow[0]);
-    d = d - (w1[1] * D.d[1 * 4 + m] + quad_bcast<1>(w2[m]) * L.drow[1]);
-    d = d - (w1[2] * D.d[2 * 4 + m] + quad_bcast<2>(w2[m]) * L.drow[2]);
-    d = d - (w1[3] * D.d[3 * 4 + m] + quad_bcast<3>(w2[m]) * L.drow[3]);
+    d = d - fma(quad_bcast<0>(w2[m]), L.drow[0], w1[0] * D.d[0 * 4 + m]);
+    d = d - fma(quad_bcast<1>(w2[m]), L.drow[1], w1[1] * D.d[1 * 4 + m]);
+    d = d - fma(quad_bcast<2>(w2[m]), L.drow[2], w1[2] * D.d[2 * 4 + m]);
+    d = d - fma(quad_bcast<3>(w2[m]), L.drow[3], w1[3] * D.d[3 * 4 + m]);
     lap[m] = d;
   }
 }

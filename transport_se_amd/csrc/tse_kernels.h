@@ -347,6 +347,7 @@ struct GatherArgs {
   const int* pering;               // [npatch][NER] elements around the patch (>= nelemd: received entry nelemd + i, stored behind the local elements)
   const unsigned char* pnb;        // [npatch][PS][8] neighbour d of a slot -> entry of the bounds image (slot, PS + ring entry, 255 = none)
   const unsigned long long* pperm; // [slot] point order inside the slot (ppos)
+  const unsigned char* pexp;       // [slot] exported lines of the slot (row_store_setup); null: every point is stored
 };
 // bounds image of the stage-3 kernel: [buffer][element entry: the patch's slots, then the element ring][min|max][level of the chunk]
 template <int PSZ> struct BoundsLds { static constexpr int ENT = PSZ + NER; double v[2][ENT][2][CL]; };   // 6-8 KB
@@ -526,19 +527,25 @@ __device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds<PSZ>& L,
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
 // stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
-struct RowStore { unsigned o0, o1; };   // plane-relative offsets (doubles) of the lane's two stores
-__device__ __forceinline__ RowStore row_store_setup(Scr S, const unsigned long long* __restrict__ pperm, int slot, int j, int k) {
+struct RowStore { unsigned o0, o1; bool s0, s1; };   // plane-relative offsets (doubles) of the lane's two stores, and whether each is made
+// pexp (k_lap1<1> only): lines of the slot that hold points some other patch or rank reads (tse_api.hip: slot_perm puts every exported
+// edge into the slot's first lines); the store of a point beyond them is dropped -- nobody reads the first Laplacian of such a point
+// from memory (k_advance<2,3> forms the Laplacian of its own slots itself), so k_lap1 writes a quarter of the field instead of all of it
+__device__ __forceinline__ RowStore row_store_setup(Scr S, const unsigned long long* __restrict__ pperm, int slot, int j, int k,
+                                                    const unsigned char* __restrict__ pexp = nullptr) {
   const int p0 = j * 4 + ((k & 1) ? 2 : 0);
   const unsigned base = (unsigned)(k / CL) * S.cse + (unsigned)slot * 16;
   const unsigned long long perm = pperm[slot];
-  return RowStore{(base + ppos(perm, p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(perm, p0 + 1)) * CL + ((k & (CL - 1)) & ~1)};
+  const int lim = pexp ? 4 * (int)pexp[slot] : 16;   // positions below `lim` are stored (whole lines)
+  return RowStore{(base + ppos(perm, p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(perm, p0 + 1)) * CL + ((k & (CL - 1)) & ~1),
+                  ppos(perm, p0) < lim, ppos(perm, p0 + 1) < lim};
 }
 __device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[q][0] */, const RowStore& R, int k, bool live, const double v[4]) {
   const bool odd = k & 1;
   const double r0 = swz_xor4(odd ? v[0] : v[2]), r1 = swz_xor4(odd ? v[1] : v[3]);
   if (live) {
-    *reinterpret_cast<double2*>(plane + R.o0) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
-    *reinterpret_cast<double2*>(plane + R.o1) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
+    if (R.s0) *reinterpret_cast<double2*>(plane + R.o0) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
+    if (R.s1) *reinterpret_cast<double2*>(plane + R.o1) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
   }
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
@@ -607,6 +614,9 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
 #ifndef TSE_ADV2_LDSC
 #define TSE_ADV2_LDSC 0   // A/B: the level-independent per-(element, point) constants of stage 3 (rm, the Laplacian's A B C, rspheremp) in LDS instead of registers
 #endif
+  // Stage 3 forms the first Laplacian and the element bounds of its patch's OWN slots itself (OWNLAP; below): k_lap1 only has to
+  // leave what other patches and ranks read
+  constexpr bool OWNLAP = GIN == 3;
   constexpr bool LDSC = TSE_ADV2_LDSC && GIN == 3;
   __shared__ double cst_[LDSC ? 5 : 1][LDSC ? PSZ * 16 : 1];
   constexpr int BND_ENT = BoundsLds<PSZ>::ENT, LDS_ZERO = Patch<PSZ>::LDS_ZERO;
@@ -669,7 +679,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      dpk[i] = dpk[i] - RHS * dt * t0[i];
+      dpk[i] = dp_stage(dpk[i], RHS * dt, t0[i]);   // (shared with k_lap1: the two must agree on dp of stage 3 to the bit)
       dps[i] = dpk[i] - dt * t1[i];
       rdps[i] = 1.0 / dps[i];
       rdpk[i] = 1.0 / dpk[i];
@@ -698,11 +708,14 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   const double* bbase = qmin;
   if (NBR) {
     const int t = threadIdx.x, u = min(t >> 2, BND_ENT - 1), w = (t >> 1) & 1, h = t & 1;   // lanes beyond the image repeat its last entry
-    int el = u < PSZ ? GA.pslots[pid.patch * PSZ + u] : GA.pering[pid.patch * NER + (u - PSZ)];
+    // (the bounds of the patch's own slots are formed in this kernel: the lanes that would load them repeat the first ring entry --
+    // same address, same LDS word, same value)
+    const int ul = u < PSZ ? PSZ : u;
+    int el = GA.pering[pid.patch * NER + (ul - PSZ)];
     if (el < 0) el = pid.e;   // hole
     bsrc = (unsigned)((((size_t)el * NCHUNK + kc / CL) * mm_qpad(qsize)) * CL + h * 2);   // + q*CL: entry index in qmin / qmax (< 2^32: the arrays are < 32 GB)
     bbase = w ? qmax : qmin;
-    bdst = (unsigned)(((u * 2 + w) * CL + h * 2) * 8);
+    bdst = (unsigned)(((ul * 2 + w) * CL + h * 2) * 8);
     // the 9 entries of a slab (its element, then the 8 neighbours) are shared out over the quad: row j takes entries j, j+4 (and 8)
     const int sl = pid.live ? pid.tslot - pid.patch * PSZ : 0, kk = kc & (CL - 1);
 #pragma unroll
@@ -735,13 +748,17 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     // API, where qmin/qmax are visible state) write them back
     if (GIN == 0 && k < NLEV && j == 0 && o.ch) { const size_t m = mm_idx(e, q, k, qsize); qmin[m] = o.mn; qmax[m] = o.mx; }
   };
-  GatherRaw graw, graw2;
+  GatherRaw graw;
+  double2 lring = make_double2(0., 0.);                  // OWNLAP: the lane's ring load of the first Laplacian
   double2 braw = make_double2(0., 0.);                   // NBR: the lane's piece of the bounds image                                 // raw own / ring loads of the gathered input(s) (DSS on read)
   double qnx[4] = {0, 0, 0, 0}, lsx[4] = {0, 0, 0, 0}, minx = 0.0, maxx = 0.0;   // plainly loaded inputs of the next tracer
   auto fetch = [&](int q) {   // loads only
     const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4, mi = mm_idx(e, q, kc, qsize);
     if (GIN) gather_issue(RG, GA, Qn0, q, graw);              // GIN == 3: graw <- Qn0 (tracers), graw2 <- lap
-    if (GIN == 3) gather_issue(RG, GA, lap, q, graw2);
+    if (OWNLAP) {   // of the first Laplacian only the patch's halo ring comes from memory (what k_lap1 left of it: the exported lines)
+      asm volatile("" : "+v"(RG.ring));
+      lring = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(lap + (size_t)q * GA.S.tps) + RG.ring);
+    }
     if (GIN == 0) load4(Qn0 + so, qnx);
     if (RHS == 2 && GIN != 3) load4(lap + so, lsx);
     if (NBR) braw = *reinterpret_cast<const double2*>(bbase + ((size_t)bsrc + (size_t)q * CL));
@@ -754,7 +771,10 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   auto step = [&](int q, const Out* prev, int qprev, Out& cur) {
     double qn[4], ls[4] = {0, 0, 0, 0}, own[4], own2[4], minp = minx, maxp = maxx;
     if (GIN) gather_publish(RG, lds_[0], q & 1, kc, graw, own);
-    if (GIN == 3) gather_publish(RG, lds_[GIN == 3 ? 1 : 0], q & 1, kc, graw2, own2);
+    if (OWNLAP) {
+      *reinterpret_cast<double2*>(reinterpret_cast<char*>(&lds_[GIN == 3 ? 1 : 0].v[q & 1][0][0]) + RG.lwr) = lring;
+      asm volatile("" : : : "memory");   // (written before the next tracer's load reuses lring)
+    }
     if (NBR) {
       *reinterpret_cast<double2*>(reinterpret_cast<char*>(&bnd_.v[q & 1][0][0][0]) + bdst) = braw;
       asm volatile("" : : : "memory");   // (written before the next tracer's load reuses braw)
@@ -780,10 +800,25 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
         RowGather Rt = RG;
         ldsc4(4, Rt.rs);
         gather_sum(Rt, lds_[0], q & 1, j, own, qn);
-        gather_sum(Rt, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
       } else {
       gather_sum(RG, lds_[0], q & 1, j, own, qn);
-      if (GIN == 3) gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
+      }
+      if (OWNLAP) {
+        // What k_lap1 does for a slab (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389), for the patch's own slots:
+        // Q = Qdp/dp, element min/max, first weak Laplacian -- published in the second image / the bounds image, whose ring parts came
+        // from memory.  Same routines on the same assembled tracers as in k_lap1 (lap_q_of, laplace_lean_row: no contraction left to
+        // the compiler), so a point's Laplacian is the same bits whether its own block formed it or a neighbour read it from T.
+        double x1[4];
+        lap_q_of(qn, rdpk, x1);
+        const double emn = quad_min(fmin(fmin(x1[0], x1[1]), fmin(x1[2], x1[3]))), emx = quad_max(fmax(fmax(x1[0], x1[1]), fmax(x1[2], x1[3])));
+        laplace_lean_row(D, L, x1, own2);
+        const int sl = threadIdx.x >> 4, kk = kc & (CL - 1);
+        char* im = reinterpret_cast<char*>(&lds_[GIN == 3 ? 1 : 0].v[q & 1][0][0]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) *reinterpret_cast<double*>(im + (lds_own_entry(sl, j * 4 + i) * CL + kk) * 8) = own2[i];
+        if (j == 0) { bnd_.v[q & 1][sl][0][kk] = emn; bnd_.v[q & 1][sl][1][kk] = emx; }
+        lds_barrier();
+        gather_sum(RG, lds_[GIN == 3 ? 1 : 0], q & 1, j, own2, ls);
       }
     }
     if (NBR) {   // viscosity_mod.F90:429-432 on the element bounds k_lap1 left in qmin/qmax
@@ -892,7 +927,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
     const SlabId sid = flat_slab(GA.nwork, GA.order);
     e = sid.e; kc = sid.k; k = sid.live ? sid.k : NLEV; slot = GA.slot_of[e];
   }
-  const RowStore RS = row_store_setup(GA.S, GA.pperm, slot, j, kc);
+  const RowStore RS = row_store_setup(GA.S, GA.pperm, slot, j, kc, GIN ? GA.pexp : nullptr);
   LapGeo L;
   {
     RowGeo g;
@@ -903,7 +938,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
   double dpk[4], dv[4];
   load4(dp + lo, dpk); load4(divdp_proj + lo, dv);
 #pragma unroll
-  for (int i = 0; i < 4; i++) dpk[i] = 1.0 / (dpk[i] - rdt * dv[i]);
+  for (int i = 0; i < 4; i++) dpk[i] = 1.0 / dp_stage(dpk[i], rdt, dv[i]);   // (the same routine as in k_advance<2,3>: tse_device.h)
   RowGather RG;
   GatherRaw graw;
   if (GIN) {
@@ -920,8 +955,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
       const size_t so = (((size_t)e * qsize + q) * NLEV + kc) * 16 + j * 4;
       double x[4], l1[4];
       load4(Qn0 + so, x);
-#pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
+      lap_q_of(x, dpk, x);
       double mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
       double mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
       laplace_lean_row(D, L, x, l1);
@@ -952,8 +986,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS) void k_la
     lds_barrier();
     if ((q & 3) == 0 && q) flush_bounds(stg_, (q >> 2) - 1, GA.pslots, pid.patch, kc / CL, qsize, qmin, qmax);   // the element bounds of the 4 tracers before
     gather_sum(RG, lds_, q & 1, j, own, x);
-#pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = x[i] * dpk[i];
+    lap_q_of(x, dpk, x);
     cur.mn = quad_min(fmin(fmin(x[0], x[1]), fmin(x[2], x[3])));
     cur.mx = quad_max(fmax(fmax(x[0], x[1]), fmax(x[2], x[3])));
     stage_bounds(stg_, q, cur.mn, cur.mx);
