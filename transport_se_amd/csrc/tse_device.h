@@ -29,6 +29,14 @@ __device__ __forceinline__ double dppq(double x) {
 // broadcast quad lane M to the 4 lanes of the quad
 template <int M>
 __device__ __forceinline__ double quad_bcast(double x) { return dppq<M * 0x55>(x); }
+// the value of quad lane (j + R) & 3, j = the lane's own position in the quad: quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2].
+// A sum over the 4 rows of a slab needs the lane's own row and these three: 3 cross-lane moves per value where broadcasting all four
+// rows takes 4 (the own row needs none) -- the y-derivatives' moves are a third of the stage-3 kernel's vector instructions.
+template <int R>
+__device__ __forceinline__ double quad_rot(double x) {
+  static_assert(R >= 1 && R <= 3, "rotation by 1, 2 or 3 lanes");
+  return dppq<R == 1 ? 0x39 : R == 2 ? 0x4E : 0x93>(x);
+}
 // butterfly reductions over the 4 lanes of a quad; every lane ends with the bit-identical result
 __device__ __forceinline__ double quad_sum(double x) { x += dppq<0xB1>(x); x += dppq<0x4E>(x); return x; }
 __device__ __forceinline__ double quad_min(double x) { x = fmin(x, dppq<0xB1>(x)); x = fmin(x, dppq<0x4E>(x)); return x; }
@@ -49,8 +57,9 @@ __device__ __forceinline__ void store4(double* __restrict__ p, const double v[4]
 struct RowGeo {
   double Di11[4], Di21[4], Di12[4], Di22[4];  // Dinv(a,b,i,j)
   double metdet[4], rmetdet[4], spheremp[4];
-  double dcol[4];  // dcol[m] = Dvv(m, j)   (sum over the row index in d/dy)
-  double drow[4];  // drow[m] = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
+  // in ROTATION order (quad_rot): entry r belongs to row m = (j + r) & 3 -- the lane's own row first, then the rows the three rotations bring
+  double dcol[4];  // dcol[r] = Dvv(m, j)   (sum over the row index in d/dy)
+  double drow[4];  // drow[r] = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
 };
 
 // dvv: a device copy of Dvv.  The lane's column/row of Dvv are loaded from it rather than selected out of the by-value
@@ -68,9 +77,8 @@ __device__ __forceinline__ void load_row_geo(RowGeo& g, const double* __restrict
   load4(metdet + (size_t)e * 16 + j * 4, g.metdet);
   load4(rmetdet + (size_t)e * 16 + j * 4, g.rmetdet);
   load4(spheremp + (size_t)e * 16 + j * 4, g.spheremp);
-  load4(dvv + j * 4, g.dcol);
 #pragma unroll
-  for (int m = 0; m < 4; m++) g.drow[m] = dvv[m * 4 + j];
+  for (int r = 0; r < 4; r++) { const int m = (j + r) & 3; g.dcol[r] = dvv[j * 4 + m]; g.drow[r] = dvv[m * 4 + j]; }
 }
 
 // dx[l] = sum_i Dvv(i,l) a[i]  (in-register) ;  dy[i] = sum_m Dvv(m,j) b(i,m)  (quad broadcast of rows)
@@ -83,15 +91,12 @@ __device__ __forceinline__ void deriv_xy(const Dvv_t& D, const RowGeo& g, const 
     for (int i = 0; i < 4; i++) s = s + D.d[l * 4 + i] * a[i];
     dx[l] = s;
   }
-  double r0[4], r1[4], r2[4], r3[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    r0[i] = quad_bcast<0>(b[i]); r1[i] = quad_bcast<1>(b[i]); r2[i] = quad_bcast<2>(b[i]); r3[i] = quad_bcast<3>(b[i]);
-  }
+  // (the rows are added own row first, then in rotation order -- the reference adds them in row order 1..np, derivative_mod.F90:2395-2406;
+  // the same four terms)
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     double s = 0.0;
-    s = s + g.dcol[0] * r0[i]; s = s + g.dcol[1] * r1[i]; s = s + g.dcol[2] * r2[i]; s = s + g.dcol[3] * r3[i];
+    s = s + g.dcol[0] * b[i]; s = s + g.dcol[1] * quad_rot<1>(b[i]); s = s + g.dcol[2] * quad_rot<2>(b[i]); s = s + g.dcol[3] * quad_rot<3>(b[i]);
     dy[i] = s;
   }
 }
@@ -152,17 +157,17 @@ __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const double dx = fma(D.d[i * 4 + 3], s[3], fma(D.d[i * 4 + 2], s[2], fma(D.d[i * 4 + 1], s[1], D.d[i * 4] * s[0])));
-    const double dy = fma(L.dcol[3], quad_bcast<3>(s[i]), fma(L.dcol[2], quad_bcast<2>(s[i]), fma(L.dcol[1], quad_bcast<1>(s[i]), L.dcol[0] * quad_bcast<0>(s[i]))));
+    const double dy = fma(L.dcol[3], quad_rot<3>(s[i]), fma(L.dcol[2], quad_rot<2>(s[i]), fma(L.dcol[1], quad_rot<1>(s[i]), L.dcol[0] * s[i])));
     w1[i] = fma(L.B[i], dy, L.A[i] * dx);
     w2[i] = fma(L.C[i], dy, L.B[i] * dx);
   }
 #pragma unroll
   for (int m = 0; m < 4; m++) {
     double d = 0.0;
-    d = d - fma(quad_bcast<0>(w2[m]), L.drow[0], w1[0] * D.d[0 * 4 + m]);
-    d = d - fma(quad_bcast<1>(w2[m]), L.drow[1], w1[1] * D.d[1 * 4 + m]);
-    d = d - fma(quad_bcast<2>(w2[m]), L.drow[2], w1[2] * D.d[2 * 4 + m]);
-    d = d - fma(quad_bcast<3>(w2[m]), L.drow[3], w1[3] * D.d[3 * 4 + m]);
+    d = d - fma(w2[m], L.drow[0], w1[0] * D.d[0 * 4 + m]);                  // (each x-term paired with one y-term: own row, then the rotations)
+    d = d - fma(quad_rot<1>(w2[m]), L.drow[1], w1[1] * D.d[1 * 4 + m]);
+    d = d - fma(quad_rot<2>(w2[m]), L.drow[2], w1[2] * D.d[2 * 4 + m]);
+    d = d - fma(quad_rot<3>(w2[m]), L.drow[3], w1[3] * D.d[3 * 4 + m]);
     lap[m] = d;
   }
 }

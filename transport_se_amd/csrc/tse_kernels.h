@@ -859,15 +859,9 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
       for (int i = 0; i < 4; i++) sm = sm + D.d[l * 4 + i] * gv1[i];
       dx[l] = sm;
     }
-    {
-      double r0[4], r1[4], r2[4], r3[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        r0[i] = quad_bcast<0>(gv2[i]); r1[i] = quad_bcast<1>(gv2[i]); r2[i] = quad_bcast<2>(gv2[i]); r3[i] = quad_bcast<3>(gv2[i]);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) dy[i] = ((dcol[0] * r0[i] + dcol[1] * r1[i]) + dcol[2] * r2[i]) + dcol[3] * r3[i];
-    }
+    for (int i = 0; i < 4; i++)   // own row, then the three rotations (dcol is in that order: load_row_geo)
+      dy[i] = ((dcol[0] * gv2[i] + dcol[1] * quad_rot<1>(gv2[i])) + dcol[2] * quad_rot<2>(gv2[i])) + dcol[3] * quad_rot<3>(gv2[i]);
 #endif
     double rmv[4];
     if (LDSC) ldsc4(0, rmv);
