@@ -590,16 +590,14 @@ __global__ void k_zero_slot(int qsize, double* __restrict__ dst, Scr S, unsigned
 // Laplacian of the biharmonic and its scaling (viscosity_mod.F90:419-423 + prim_advection_mod.F90:813-826);
 // `lap` then holds rspheremp*DSS(laplace_sphere_wk(Q)).
 // GIN: DSS on read (whole-step path; block = patch x chunk, see above).  1: the tracer input is rspheremp*DSS of the previous
-// stage's pre-DSS scratch (passed in Qn0, scratch layout); 3: so is the Laplacian input `lap` (RHS == 2) -- stage 3 then never
-// needs the DSS'd stage-2 tracers in memory (k_lap1 does not store them).
+// stage's pre-DSS scratch (passed in Qn0, scratch layout); 3 (RHS == 2): in addition the DSS'd first Laplacian is assembled here --
+// its own slots' values are FORMED here from the stage-2 tracers just assembled (OWNLAP below), only the halo ring comes from `lap`
+// (the exported lines k_lap1<1> stored) -- and so are the element bounds.  Stage 3 never needs the DSS'd stage-2 tracers in memory.
 // Register tiers (512 VGPRs per SIMD lane): 128 -> 4 waves, 168 -> 3, 256 -> 2.  Forcing the stage-2 DSS-on-read kernel
 // (170) into the 3-wave tier with amdgpu_waves_per_eu costs 2 spills and gains nothing measurable.
 template <int RHS, int GIN = 0, bool DB = (GIN != 0), int PSZ = 16 /* block shape (GIN != 0): Patch<PSZ> */>
 #ifndef TSE_ADV2_WPE
 #define TSE_ADV2_WPE 1   // A/B: minimum waves per SIMD asked of the compiler for k_advance<2,3,.,16> (3 = the 168-register tier)
-#endif
-#ifdef TSE_ADV2_NVGPR   // A/B: cap the registers of every k_advance instance of the translation unit (tse_stage3.hip holds only <2,3>)
-__attribute__((amdgpu_waves_per_eu(TSE_ADV2_NVGPR, TSE_ADV2_NVGPR)))
 #endif
 __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3 && PSZ == 16) ? TSE_ADV2_WPE : 1) void k_advance(int nelemd, Dvv_t D, GeoPtrs G, int qsize, double dt, double nu_q,
                                                           const double* __restrict__ Qn0, const double* __restrict__ lap,
@@ -611,14 +609,9 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
   static_assert(GIN != 0 || PSZ == 16, "the plain kernels have no block shape");
   __shared__ PatchLds<PSZ> lds_[GIN == 3 ? 2 : 1];   // (unused and removed by the compiler when GIN == 0)
   __shared__ BoundsLds<PSZ> bnd_;                    // (GIN == 3 only)
-#ifndef TSE_ADV2_LDSC
-#define TSE_ADV2_LDSC 0   // A/B: the level-independent per-(element, point) constants of stage 3 (rm, the Laplacian's A B C, rspheremp) in LDS instead of registers
-#endif
   // Stage 3 forms the first Laplacian and the element bounds of its patch's OWN slots itself (OWNLAP; below): k_lap1 only has to
   // leave what other patches and ranks read
   constexpr bool OWNLAP = GIN == 3;
-  constexpr bool LDSC = TSE_ADV2_LDSC && GIN == 3;
-  __shared__ double cst_[LDSC ? 5 : 1][LDSC ? PSZ * 16 : 1];
   constexpr int BND_ENT = BoundsLds<PSZ>::ENT, LDS_ZERO = Patch<PSZ>::LDS_ZERO;
   static_assert(BND_ENT * 4 <= Patch<PSZ>::THREADS, "one 16-byte load per lane fills the bounds image");
   constexpr bool NBR = GIN == 3;                // the limiter bounds are the min/max over the element and its neighbours of qmin/qmax, formed here
@@ -693,15 +686,6 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     if (RHS == 2) make_lap_geo(L, g);
   }
-  const int cidx = LDSC ? (int)((threadIdx.x >> 4) * 16 + j * 4) : 0;
-  if (LDSC && ((threadIdx.x >> 2) & (CL - 1)) == 0) {   // (read behind the first tracer's barrier)
-#pragma unroll
-    for (int i = 0; i < 4; i++) { cst_[0][cidx + i] = rm[i]; cst_[1][cidx + i] = L.A[i]; cst_[2][cidx + i] = L.B[i]; cst_[3][cidx + i] = L.C[i]; cst_[4][cidx + i] = RG.rs[i]; }
-  }
-  auto ldsc4 = [&](int cI, double v[4]) __attribute__((always_inline)) {
-    const double2 a = *reinterpret_cast<const double2*>(&cst_[cI][cidx]), b = *reinterpret_cast<const double2*>(&cst_[cI][cidx + 2]);
-    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-  };
   // NBR: per tracer the block loads the bounds of its patch's elements and of the element ring (lane = 16 bytes: entry, min|max,
   // level pair) into LDS with the tracer's other loads; after the barrier a lane reads its element's and its 8 neighbours' values
   unsigned bsrc = 0, bdst = 0, bnb[3] = {0, 0, 0};
@@ -796,13 +780,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     __builtin_amdgcn_sched_barrier(0);
     if (GIN) {
       lds_barrier();
-      if (LDSC) {
-        RowGather Rt = RG;
-        ldsc4(4, Rt.rs);
-        gather_sum(Rt, lds_[0], q & 1, j, own, qn);
-      } else {
       gather_sum(RG, lds_[0], q & 1, j, own, qn);
-      }
       if (OWNLAP) {
         // What k_lap1 does for a slab (prim_advection_mod.F90:750-761,796-809 + viscosity_mod.F90:378-389), for the patch's own slots:
         // Q = Qdp/dp, element min/max, first weak Laplacian -- published in the second image / the bounds image, whose ring parts came
@@ -833,13 +811,6 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
-      if (LDSC) {
-        LapGeo Lt;
-        ldsc4(1, Lt.A); ldsc4(2, Lt.B); ldsc4(3, Lt.C);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { Lt.dcol[i] = L.dcol[i]; Lt.drow[i] = L.drow[i]; }
-        laplace_lean_row(D, Lt, ls, bih);
-      } else
       laplace_lean_row(D, L, ls, bih);
 #pragma unroll
       for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
@@ -863,14 +834,8 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     for (int i = 0; i < 4; i++)   // own row, then the three rotations (dcol is in that order: load_row_geo)
       dy[i] = ((dcol[0] * gv2[i] + dcol[1] * quad_rot<1>(gv2[i])) + dcol[2] * quad_rot<2>(gv2[i])) + dcol[3] * quad_rot<3>(gv2[i]);
 #endif
-    double rmv[4];
-    if (LDSC) ldsc4(0, rmv);
-    else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) rmv[i] = rm[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) x[i] = qn[i] - rmv[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
+    for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
     bool changed = false;
     if (RHS == 1) {
       double q0 = qn[0] * rdpk[0], q1 = qn[1] * rdpk[1], q2 = qn[2] * rdpk[2], q3 = qn[3] * rdpk[3];
