@@ -59,10 +59,11 @@ def test_remap_q_ppm_single_call(ref_ctx, gold, monkeypatch, generic):
     out = hip.remap_q_ppm(q, dp1, dp2)
     ref = g["remap_Qout"][which]
     # the accepted bound of ONE remap_Q_ppm call against the reference's own output (the kernel folds the ten PPM grid coefficients into
-    # five and multiplies by reciprocals: relative 1e-16 per level): 5e-13 of the field maximum
+    # five and multiplies by reciprocals: relative 1e-16 per level): 1e-13 of the field maximum
     from conftest import record_margin
-    record_margin("remap_q_ppm single call vs reference (generic=%d)" % generic, np.abs(out - ref).max() / np.abs(ref).max(), 5e-13)
-    assert np.abs(out - ref).max() <= 5e-13 * np.abs(ref).max(), np.abs(out - ref).max() / np.abs(ref).max()
+    # measured 1.8e-15 (profiles/r04_test_margins.jsonl); asserted 1e-13 (round 3: 5e-13)
+    record_margin("remap_q_ppm single call vs reference (generic=%d)" % generic, np.abs(out - ref).max() / np.abs(ref).max(), 1e-13)
+    assert np.abs(out - ref).max() <= 1e-13 * np.abs(ref).max(), np.abs(out - ref).max() / np.abs(ref).max()
     np.testing.assert_allclose(out.sum(2), q.sum(2), rtol=1e-13)    # column mass (pin(nlev+1) = pio(nlev+1), :144)
 
 
