@@ -179,7 +179,8 @@ int tse_dcmip_init(tse_ctx *ctx, int test_case /*1: dcmip1-1, 2: dcmip1-2*/, con
 int tse_dcmip_set_initial(tse_ctx *ctx);
 /* what prim_step + prim_advance_exp produce for the step that starts at tl%nstep = nstep */
 int tse_dcmip_step_inputs(tse_ctx *ctx, int nstep, double tstep);
-/* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out.
+/* prim_run_subcycle x nsub: rsplit x (step inputs + tracer step) + vertical_remap; *nstep is tl%nstep in/out.  *nstep may lie inside
+ * an rsplit cycle (steps taken through tse_advec_tracers_remap_rk2): the first of the nsub cycles then completes that cycle.
  * Returns 2 on "negative layer thickness" (prim_advection_mod.F90:1323) with *nstep = the step count at the end of the FIRST
  * failing cycle; the flag is polled two cycles behind the launches (the host never waits for the device), so up to two
  * further cycles may have been started on the bad state.  Several ranks: escalate as for tse_vertical_remap. */

@@ -391,3 +391,22 @@ def test_remap_that_assembles_the_last_dss_on_read_leaves_the_bits_of_the_two_ke
         done, _ = o.prim_run(1, dt, 2)
         assert done == 6 and relerr(out["1"]["qdp"][0], o.qdp[0]) < 10 * TOL_STEP
     o.close()
+
+
+def test_chunking_of_the_run_does_not_move_a_bit():
+    """driver.PrimRun.run() hands whole rsplit cycles to tse_prim_run_subcycle -- which completes a cycle under way first (the remap that
+    closes it assembles the last step's DSS on read) -- and takes what is left step by step through the public entries
+    (tse_advec_tracers_remap_rk2 + tse_vertical_remap: the two-kernel route).  However a run is cut into calls, the bits are the same:
+    bench.py's `--warmup 5 --steps 20` is 25 steps."""
+    import torch
+    from transport_se_amd.driver import PrimRun
+    out = []
+    for chunks in ((25,), (5, 20), (1, 1, 7, 16), (4, 1, 1, 19)):
+        run = PrimRun(4, 3, test_case=1, device=0, torch_mod=torch)
+        for n in chunks:
+            np1 = run.run(n)
+        assert run.nstep == 25 and np1 == 2
+        out.append(run.hip.fetch("qdp", (2, run.nelem, 3, 72, 4, 4)).copy())
+        run.close()
+    for o in out[1:]:
+        assert np.array_equal(o.view(np.uint64), out[0].view(np.uint64))

@@ -1723,8 +1723,11 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
   // has long landed, so the host never waits for the device while it keeps a full cycle queued ahead -- and the call returns 2
   // with *nstep = the step count at the end of the failing cycle (at most two more cycles were started on the bad state).
   // (With the callback form of the halo exchange every stage synchronises with the host anyway.)
+  // (*nstep may lie inside an rsplit cycle -- a caller that stepped part of it through the step-by-step entries: the first of the nsub
+  // cycles is then the REST of that cycle, rsplit - nstep % rsplit steps and its remap)
+  const int r0 = ((nstep0 % c->rsplit) + c->rsplit) % c->rsplit;
   auto failed = [&](int cyc) -> int {
-    *nstep_io = nstep0 + (cyc + 1) * c->rsplit;
+    *nstep_io = nstep0 - r0 + (cyc + 1) * c->rsplit;
     set_bounds_cache(c, 0);
     (void)hipStreamSynchronize(c->stream);
     (void)hipMemset(c->bad, 0, sizeof(int));
@@ -1740,7 +1743,7 @@ int tse_prim_run_subcycle(tse_ctx* c, double tstep, int nsub, int* nstep_io) {
       if (c->bad_host[s & 1]) return failed(s - 2);
     }
     int n0 = 1, np1 = 2;
-    for (int r = 0; r < c->rsplit; r++) {
+    for (int r = (s == 0 ? r0 : 0); r < c->rsplit; r++) {
       if (overlap_inputs) {   // fork: behind everything launched so far (the previous step / remap read what this writes)
         HIPCHK(hipEventRecord(c->ev_fork, c->stream));
         HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));

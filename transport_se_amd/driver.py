@@ -196,12 +196,16 @@ class PrimRun:
     def run(self, nsteps):
         """nsteps prim_steps; whole rsplit cycles go through the device-resident loop (no host synchronisation inside)"""
         np1 = 2
-        while nsteps > 0 and self.nstep % self.rsplit:
-            np1 = self.step(); nsteps -= 1
-        ncyc = nsteps // self.rsplit
+        lead = (self.rsplit - self.nstep % self.rsplit) % self.rsplit     # steps that complete the cycle under way
+        if lead > nsteps:                                                 # ... which this call does not reach: step by step
+            lead = 0
+            while nsteps > 0:
+                np1 = self.step(); nsteps -= 1
+        ncyc = (1 if lead else 0) + (nsteps - lead) // self.rsplit       # (the device-resident loop completes a cycle under way first)
         if ncyc:
+            before = self.nstep
             self.nstep = self.hip.prim_run_subcycle(self.tstep, ncyc, self.nstep)
-            nsteps -= ncyc * self.rsplit
+            nsteps -= self.nstep - before
             np1 = 2 if (self.nstep - 1) % 2 == 0 else 1        # the last step wrote 3 - n0, n0 = 1 + mod(nstep, 2)
         for _ in range(nsteps):
             np1 = self.step()
