@@ -98,3 +98,32 @@ def test_remap_segment_tasks_and_generic_loop_leave_the_bits_of_a_whole_sweep(mo
         assert np.array_equal(out, gen), "generic column loop differs from the lockstep loop (qsize %d)" % qsize
         np.testing.assert_allclose(out.sum(2), Q.sum(2), rtol=1e-13)
         hip.close()
+
+
+def test_element_qdiag_is_prim_diag_scalars_and_global_integral():
+    """tse_element_qdiag: the element shares of prim_diag_scalars' Qmass / Qvar (prim_state_mod.F90:604-655: sum_k Qdp and sum_k Qdp*Q per
+    point, Q = Qdp/dp with dp = dhyai*ps0 + dhybi*ps_v, prim_driver_mod.F90:810-815) integrated as global_integral does
+    (global_norms_mod.F90:74-80: sum over the points of spheremp*h, i fastest) and the element extrema of Q -- against the same
+    operations in numpy, in the same order (sequential sums), to the last bits a different FMA choice can move."""
+    import pyoracle as po
+    from gpu_common import elem_from_oracle, make_hip
+    o = po.Oracle(3, 5, nu_q=2e18)
+    elem = elem_from_oracle(o)
+    hip = make_hip(o, elem)
+    hip.dcmip_init(1, o.lat, o.lon, o.hyam, o.hybm); hip.dcmip_set_initial()
+    assert hip.prim_run_subcycle(900.0, 1, 0) == 3
+    qdp = hip.fetch("qdp", (2, o.nelem, 5, 72, 4, 4))[1]
+    ps_v = hip.fetch("ps_v", (o.nelem, 4, 4))
+    mass, var, qmn, qmx = hip.element_qdiag(2)
+    dp = (np.diff(o.hyai) * 1.0e5)[None, :, None, None] + np.diff(o.hybi)[None, :, None, None] * ps_v[:, None]
+    q = qdp / dp[:, None]
+    hm = np.zeros((o.nelem, 5, 4, 4)); hv = np.zeros_like(hm)
+    for k in range(72):                                   # levels inside a point, in order
+        hm = hm + qdp[:, :, k]; hv = hv + qdp[:, :, k] * q[:, :, k]
+    jm = np.zeros((o.nelem, 5)); jv = np.zeros_like(jm)
+    for p in range(16):                                   # then the points, i fastest
+        w = o.spheremp.reshape(o.nelem, 16)[:, p][:, None]
+        jm = jm + w * hm.reshape(o.nelem, 5, 16)[:, :, p]; jv = jv + w * hv.reshape(o.nelem, 5, 16)[:, :, p]
+    assert np.array_equal(mass, jm) and np.array_equal(var, jv)          # no contraction in the kernel: the very same roundings
+    assert np.array_equal(qmn, q.reshape(o.nelem, 5, -1).min(2)) and np.array_equal(qmx, q.reshape(o.nelem, 5, -1).max(2))
+    hip.close(); o.close()

@@ -136,6 +136,15 @@ def test_preqx_dcmip12_norm_line_equals_the_reference_run(tmp_path):
     for name in ("prim_run", "prim_advance_exp", "prim_advec_tracers", "vertical_remap"):   # run_ne120_perf.sh:140-144
         assert name in stats
     assert sum(l.startswith("qv= ") for l in out.splitlines()) >= 4 and "Q2,Q diss, dQ^2/dt:" in out   # prim_printstate's lines (prim_state_mod.F90:341-385)
+    # "One should also check that the tracer mass is conserved by looking at the Q, Q diss values" (README:38-44): '(a,i1,a,E22.14,a,2E15.7)' =
+    # mass [kg/m^2], d(mass)/dt over the cycle, d(variance)/dt -- the mass rate must vanish against mass / dt (tstep = 400 s here)
+    seen = 0
+    for l in out.splitlines():
+        if l.startswith("Q") and ",Q diss, dQ^2/dt:" in l:
+            m = float(l.split(":")[1].split("kg/m^2")[0]); rates = l.split("kg/m^2")[1].split()
+            assert len(rates) == 2 and abs(float(rates[0])) * 400.0 <= 1e-11 * max(abs(m), 1e-300), l
+            seen += 1
+    assert seen >= 4, out[-1500:]
     for l in out.splitlines():                                    # mass conserved (the "Q,Q diss" check)
         if l.startswith("Q") and "relative change" in l:
             assert abs(float(l.split("relative change")[1].strip(" )"))) < 1e-11
