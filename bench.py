@@ -91,6 +91,27 @@ def measured_traffic(ne, qsize, n_gpus, group, launches_per_step):
     return None, None, "no PMC profile of this build and workload under profiles/"
 
 
+def measured_valu(ne, qsize, n_gpus, group):
+    """vector-issue figures of the dominant kernel from the newest committed SQ-counter record of THIS build's kernel sources
+    (tools/profile_round.sh: separate rocprofv3 --pmc passes): VALU instructions per wave, the share of the wave cycles with a VALU
+    instruction in flight, waves per SIMD the kernel holds, and their product = the share of a SIMD's issue slots in use"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters*.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+            c = t["config"]
+            if (c["ne"], c["qsize"], c["n_gpus"]) != (ne, qsize, n_gpus) or t.get("kernel_source_hash") != kernel_source_hash():
+                continue
+            e = _kernel_entry(t["kernels"], KERNEL_NAMES[group])
+            wps = {"advance2": 2, "remap": 2}.get(group, 3)   # waves per SIMD the kernel's registers / LDS allow (tools/kres.sh, DESIGN.md section 3)
+            return {"insts_per_wave": round(e["valu_insts_per_wave"]), "active_frac_of_wave_cycles": e["active_inst_valu_frac_of_wave_cycles"],
+                    "waves_per_simd": wps, "issue_slot_utilisation": e["active_inst_valu_frac_of_wave_cycles"] * wps,
+                    "source": os.path.relpath(path, ROOT), "measured_in_this_run": False}
+        except Exception:  # noqa: BLE001
+            continue
+    return None
+
+
 def l2_record(ne):
     """the second half of the metric ("+ DCMIP1-1 L2 vs ref"): the 12-day DCMIP 1-1 error norm at this resolution from the newest
     committed record under profiles/ that was produced with THIS build's kernel sources (tests/test_gpu_dcmip_norms.py writes
@@ -319,6 +340,7 @@ def main():
                          # the same kernel time priced with round 3's bytes for that kernel (k_advance<2,3> then read the first Laplacian as
                          # a third field; now it computes it: fewer bytes, more VALU work, a shorter step)
                          "frac_round3_accounting": (KERNEL_BYTES_PER_DOF_R3.get(dom, KERNEL_BYTES_PER_DOF[dom]) * dof_local / 1e9) / (ms / max(n, 1) / 1e3) / HBM_PEAK_GBS if ms > 0 else 0.0,
+                         "valu": measured_valu(a.ne, a.qsize, world, dom),
                          "dominant_kernel_note": ("k_advance<2,3> forms the first Laplacian of its own slots itself since round 4: it is bound by fp64 VALU issue "
                                                   "(SQ counters in profiles/), not by HBM; whole_step_frac is the figure that tracks the step") if dom == "advance2" else None,
                          # whole step against SURVEY 8(d)'s 133.3 B per DOF-step (kept for continuity between rounds) ...

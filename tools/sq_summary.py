@@ -42,7 +42,9 @@ for k, c in sorted(acc.items()):
             if n in mean:
                 e[key] = mean[n] / wc
     res[k] = e
-json.dump({"config": {"ne": ne, "qsize": qsize, "n_gpus": ngpu},
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transport_se_amd import _lib   # the same hash bench.py prints: ties the counters to a build
+json.dump({"config": {"ne": ne, "qsize": qsize, "n_gpus": ngpu}, "kernel_source_hash": _lib.source_hash(),
            "command": "tools/pmc_passes.sh (separate rocprofv3 --pmc passes over bench.py --steps 3 --warmup 0): "
                       "{SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS} | "
                       "{SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY}", "kernels": res}, open(out, "w"), indent=1)
