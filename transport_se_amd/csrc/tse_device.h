@@ -4,7 +4,7 @@
 // 32 contiguous bytes) of a 4x4 slab; the 4 lanes of a DPP quad own the 4 rows of one slab, so a 64-wide
 // wavefront covers 16 slabs (16 consecutive levels) and reads/writes 2 KiB contiguous per instruction pair
 // (two global_load_dwordx4 per lane).  Contractions along i are in-register; contractions along j and the
-// 16-point reductions of the limiter are quad_perm DPP moves (no LDS, no ds_bpermute).
+// 16-point reductions of the limiter are quad_perm DPP moves (no LDS, no ds_bpermute): two-stage butterflies over the quad.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,13 +29,14 @@ __device__ __forceinline__ double dppq(double x) {
 // broadcast quad lane M to the 4 lanes of the quad
 template <int M>
 __device__ __forceinline__ double quad_bcast(double x) { return dppq<M * 0x55>(x); }
-// the value of quad lane (j + R) & 3, j = the lane's own position in the quad: quad_perm [1,2,3,0], [2,3,0,1], [3,0,1,2].
-// A sum over the 4 rows of a slab needs the lane's own row and these three: 3 cross-lane moves per value where broadcasting all four
-// rows takes 4 (the own row needs none) -- the y-derivatives' moves are a third of the stage-3 kernel's vector instructions.
-template <int R>
-__device__ __forceinline__ double quad_rot(double x) {
-  static_assert(R >= 1 && R <= 3, "rotation by 1, 2 or 3 lanes");
-  return dppq<R == 1 ? 0x39 : R == 2 ? 0x4E : 0x93>(x);
+// A sum over the 4 rows of a slab, out_j = sum_m M(j,m) f_m, as a two-stage butterfly: the lane gets the value of its mirror row 3-j, forms
+// the contribution of that pair of rows {j, 3-j} to its neighbour row j^1, and the two neighbours swap these partial sums -- 2 cross-lane
+// moves and 4 multiply-adds per value where own row + three rotations take 3 and 4.  c[] = M(j,j), M(j,3-j), M(j^1,j), M(j^1,3-j).
+__device__ __forceinline__ double quad_matvec(const double c[4], double f) {
+#pragma clang fp contract(off)
+  const double g = dppq<0x1B>(f);                    // row 3-j: quad_perm [3,2,1,0]
+  const double send = fma(c[3], g, c[2] * f);        // rows {j, 3-j} seen from row j^1
+  return fma(c[1], g, fma(c[0], f, dppq<0xB1>(send)));   // rows {j^1, 3-(j^1)}, then the lane's own pair
 }
 // butterfly reductions over the 4 lanes of a quad; every lane ends with the bit-identical result
 __device__ __forceinline__ double quad_sum(double x) { x += dppq<0xB1>(x); x += dppq<0x4E>(x); return x; }
@@ -57,9 +58,9 @@ __device__ __forceinline__ void store4(double* __restrict__ p, const double v[4]
 struct RowGeo {
   double Di11[4], Di21[4], Di12[4], Di22[4];  // Dinv(a,b,i,j)
   double metdet[4], rmetdet[4], spheremp[4];
-  // in ROTATION order (quad_rot): entry r belongs to row m = (j + r) & 3 -- the lane's own row first, then the rows the three rotations bring
-  double dcol[4];  // dcol[r] = Dvv(m, j)   (sum over the row index in d/dy)
-  double drow[4];  // drow[r] = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
+  // coefficients of the lane in the order quad_matvec takes them: rows j, 3-j as seen from row j, then as seen from row j^1
+  double dcol[4];  // M(j,m) = Dvv(m, j)   (sum over the row index in d/dy)
+  double drow[4];  // M(j,m) = Dvv(j, m)   (weak divergence, derivative_mod.F90:2066-2070)
 };
 
 // dvv: a device copy of Dvv.  The lane's column/row of Dvv are loaded from it rather than selected out of the by-value
@@ -78,7 +79,10 @@ __device__ __forceinline__ void load_row_geo(RowGeo& g, const double* __restrict
   load4(rmetdet + (size_t)e * 16 + j * 4, g.rmetdet);
   load4(spheremp + (size_t)e * 16 + j * 4, g.spheremp);
 #pragma unroll
-  for (int r = 0; r < 4; r++) { const int m = (j + r) & 3; g.dcol[r] = dvv[j * 4 + m]; g.drow[r] = dvv[m * 4 + j]; }
+  for (int r = 0; r < 4; r++) {
+    const int row = r < 2 ? j : (j ^ 1), m = (r & 1) ? 3 - j : j;   // M(row, m)
+    g.dcol[r] = dvv[row * 4 + m]; g.drow[r] = dvv[m * 4 + row];
+  }
 }
 
 // dx[l] = sum_i Dvv(i,l) a[i]  (in-register) ;  dy[i] = sum_m Dvv(m,j) b(i,m)  (quad broadcast of rows)
@@ -91,14 +95,9 @@ __device__ __forceinline__ void deriv_xy(const Dvv_t& D, const RowGeo& g, const 
     for (int i = 0; i < 4; i++) s = s + D.d[l * 4 + i] * a[i];
     dx[l] = s;
   }
-  // (the rows are added own row first, then in rotation order -- the reference adds them in row order 1..np, derivative_mod.F90:2395-2406;
-  // the same four terms)
+  // (the four rows meet pairwise, quad_matvec -- the reference adds them in row order 1..np, derivative_mod.F90:2395-2406; the same four terms)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    double s = 0.0;
-    s = s + g.dcol[0] * b[i]; s = s + g.dcol[1] * quad_rot<1>(b[i]); s = s + g.dcol[2] * quad_rot<2>(b[i]); s = s + g.dcol[3] * quad_rot<3>(b[i]);
-    dy[i] = s;
-  }
+  for (int i = 0; i < 4; i++) dy[i] = quad_matvec(g.dcol, b[i]);
 }
 
 // divergence_sphere (derivative_mod.F90:2364-2414) of v = (v1,v2) at the lane's 4 points
@@ -152,23 +151,21 @@ __device__ __forceinline__ void laplace_lean_row(const Dvv_t& D, const LapGeo& L
   for (int i = 0; i < 4; i++) lap[i] = (L.A[i] + L.B[i] + L.C[i]) * s[i];
   return;
 #endif
-  // written point-by-point so that only one set of 4 quad broadcasts is live at a time (register pressure)
+  // written point-by-point so that few cross-lane values are live at a time (register pressure)
   double w1[4], w2[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const double dx = fma(D.d[i * 4 + 3], s[3], fma(D.d[i * 4 + 2], s[2], fma(D.d[i * 4 + 1], s[1], D.d[i * 4] * s[0])));
-    const double dy = fma(L.dcol[3], quad_rot<3>(s[i]), fma(L.dcol[2], quad_rot<2>(s[i]), fma(L.dcol[1], quad_rot<1>(s[i]), L.dcol[0] * s[i])));
+    const double dy = quad_matvec(L.dcol, s[i]);
     w1[i] = fma(L.B[i], dy, L.A[i] * dx);
     w2[i] = fma(L.C[i], dy, L.B[i] * dx);
   }
 #pragma unroll
   for (int m = 0; m < 4; m++) {
-    double d = 0.0;
-    d = d - fma(w2[m], L.drow[0], w1[0] * D.d[0 * 4 + m]);                  // (each x-term paired with one y-term: own row, then the rotations)
-    d = d - fma(quad_rot<1>(w2[m]), L.drow[1], w1[1] * D.d[1 * 4 + m]);
-    d = d - fma(quad_rot<2>(w2[m]), L.drow[2], w1[2] * D.d[2 * 4 + m]);
-    d = d - fma(quad_rot<3>(w2[m]), L.drow[3], w1[3] * D.d[3 * 4 + m]);
-    lap[m] = d;
+    // the x-sum and the y-sum as two independent chains (9 operations per point; the reference pairs each x-term with one y-term and
+    // subtracts the pair, derivative_mod.F90:2066-2070: the same eight products)
+    const double a = fma(w1[3], D.d[3 * 4 + m], fma(w1[2], D.d[2 * 4 + m], fma(w1[1], D.d[1 * 4 + m], w1[0] * D.d[0 * 4 + m])));
+    lap[m] = -a - quad_matvec(L.drow, w2[m]);
   }
 }
 

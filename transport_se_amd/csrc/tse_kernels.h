@@ -812,8 +812,6 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     double bih[4] = {0, 0, 0, 0};
     if (RHS == 2) {   // ls = rspheremp*DSS(first Laplacian): second Laplacian and the biharmonic scaling
       laplace_lean_row(D, L, ls, bih);
-#pragma unroll
-      for (int i = 0; i < 4; i++) bih[i] = visc[i] * bih[i];
     }
     double gv1[4], gv2[4], x[4], dx[4], dy[4];
 #pragma unroll
@@ -831,8 +829,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
       dx[l] = sm;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)   // own row, then the three rotations (dcol is in that order: load_row_geo)
-      dy[i] = ((dcol[0] * gv2[i] + dcol[1] * quad_rot<1>(gv2[i])) + dcol[2] * quad_rot<2>(gv2[i])) + dcol[3] * quad_rot<3>(gv2[i]);
+    for (int i = 0; i < 4; i++) dy[i] = quad_matvec(dcol, gv2[i]);
 #endif
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = qn[i] - rm[i] * (dx[i] + dy[i]);   // Qtens = Qdp - dt*div
@@ -846,7 +843,7 @@ __global__ __launch_bounds__(GIN ? Patch<PSZ>::THREADS : FLAT_THREADS, (GIN == 3
     }
     if (RHS == 2) {
 #pragma unroll
-      for (int i = 0; i < 4; i++) x[i] = x[i] + bih[i];
+      for (int i = 0; i < 4; i++) x[i] = fma(visc[i], bih[i], x[i]);   // -rhs_viss*dt*nu_q*dp0*Qtens_biharmonic/spheremp (prim_advection_mod.F90:813-826)
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = x[i] * rdps[i];
