@@ -185,8 +185,11 @@ __device__ __forceinline__ bool limiter8_quad(double x[4], const double c[4], do
   if (!(sumc > 0.0)) return false;  // whole quad takes the same branch
   double mass = quad_sum(((c[0] * x[0] + c[1] * x[1]) + c[2] * x[2]) + c[3] * x[3]);
   const bool lo = mass < minp * sumc, hi = mass > maxp * sumc;
-  if (lo) minp = mass / sumc;
-  if (hi) maxp = mass / sumc;
+  if (__any(lo | hi)) {   // (rare: the division is skipped by the whole wave when no slab of it relaxes a bound)
+    const double r = mass / sumc;
+    if (lo) minp = r;
+    if (hi) maxp = r;
+  }
   const double tol_mass = tol_limiter * fabs(mass);
   for (int iter = 1; iter <= NP * NP - 1; iter++) {
     // clip to [minp,maxp]; the removed mass is sum (x - clipped)*c: (x-maxp)*c above, -(minp-x)*c below, +0 inside --
