@@ -106,6 +106,7 @@ struct tse_ctx {
   // in-library exchange: RCCL communicator + communication stream; elements that touch another rank / that do not
   ncclComm_t comm = nullptr;
   hipStream_t comm_stream = nullptr;
+  hipStream_t int_stream = nullptr;   // several ranks: the interior launch of a split stage runs here, beside the boundary launch's last blocks (split_stage)
   // the prescribed-wind generator of step n+1 runs beside the neighbour min/max pass that opens the step (tse_prim_run_subcycle): its own
   // stream, forked behind the last launch of step n, joined before the first kernel that reads vn0 / eta_dot_dpdn
   hipStream_t aux_stream = nullptr;
@@ -751,6 +752,8 @@ static int init_impl(tse_ctx* c, const tse_init_args* a) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));   // hi = numerically lowest = greatest priority
     HIPCHK(hipStreamCreateWithPriority(&c->comm_stream, hipStreamNonBlocking, hi));
+    if (!(hook_env("TSE_AB_SPLIT_STREAMS") && !atoi(hook_env("TSE_AB_SPLIT_STREAMS"))))   // A/B: 0 = both launches on the compute stream
+      HIPCHK(hipStreamCreateWithPriority(&c->int_stream, hipStreamNonBlocking, lo));
     c->sync_events.assign(16, nullptr);
     for (hipEvent_t& e : c->sync_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
@@ -812,6 +815,7 @@ void tse_finalize(tse_ctx* c) {
   for (hipEvent_t e : c->sync_events) if (e) (void)hipEventDestroy(e);
   if (c->ev_mm) (void)hipEventDestroy(c->ev_mm);
   if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  if (c->int_stream) { (void)hipStreamSynchronize(c->int_stream); (void)hipStreamDestroy(c->int_stream); }
   if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_inputs) (void)hipEventDestroy(c->ev_inputs);
@@ -1353,12 +1357,27 @@ static int split_stage(tse_ctx* c, const char* timer, int kidx /* whose patch ti
                        CommWork comm_work /* () on c->comm_stream */, hipEvent_t* done_out = nullptr) {
   Scope s(c, timer);
   if (!c->halo()) return launch(work_of(c, 0, kidx));
+  // The two launches touch disjoint elements and depend on the same predecessors, not on each other: the interior launch goes to a
+  // stream of its own (lower priority) that waits for what the compute stream has seen so far, so its first blocks fill the CUs the
+  // boundary launch's last, partial round of blocks leaves idle (a rank's boundary launch is 1-3 rounds of blocks); the compute stream
+  // goes on when both are done.
+  hipEvent_t evA = nullptr;
+  if (c->int_stream) { evA = next_sync_event(c); HIPCHK(hipEventRecord(evA, c->stream)); }
   if (launch(work_of(c, 1, kidx))) return 1;
   hipEvent_t evB = next_sync_event(c), evC = done_out ? c->ev_mm : next_sync_event(c);
   HIPCHK(hipEventRecord(evB, c->stream));
   HIPCHK(hipStreamWaitEvent(c->comm_stream, evB, 0));
   if (c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
-  if (launch(work_of(c, 2, kidx))) return 1;
+  if (c->int_stream) {
+    HIPCHK(hipStreamWaitEvent(c->int_stream, evA, 0));
+    std::swap(c->stream, c->int_stream);   // (the launch closures launch on c->stream)
+    const int rc = launch(work_of(c, 2, kidx));
+    std::swap(c->stream, c->int_stream);
+    if (rc) return 1;
+    hipEvent_t evI = next_sync_event(c);
+    HIPCHK(hipEventRecord(evI, c->int_stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, evI, 0));
+  } else if (launch(work_of(c, 2, kidx))) return 1;
   if (!c->comm) { if (comm_work()) return 1; HIPCHK(hipEventRecord(evC, c->comm_stream)); }
   if (done_out) *done_out = evC;
   else HIPCHK(hipStreamWaitEvent(c->stream, evC, 0));
