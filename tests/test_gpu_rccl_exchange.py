@@ -234,7 +234,7 @@ def test_rank_rehearsal_tool_runs_one_rank_of_a_partition_in_loopback():
     assert all(d["kernel_ms_per_step_timing_mode"][k] > 0 for k in ("advance0", "advance1", "advance2", "lap", "dss", "remap"))
 
 
-def _rank_share_loopback(ne, qsize, world, rank, strips, cycles=1):
+def _rank_share_loopback(ne, qsize, world, rank, strips, cycles=1, env=None, lib_path=None):
     """rank `rank` of the `world`-rank partition alone on the GPU, every neighbour slot pointed at rank 0 of a ONE-rank RCCL communicator
     (tools/rank_rehearsal.py): the real split launches, pack / ncclSend / ncclRecv / unpack on the communication stream, prefetched
     bounds exchange -- with the rank-boundary patch tiling selected by TSE_BOUNDARY_STRIPS.  Returns (Qdp bits of both time levels
@@ -252,10 +252,12 @@ def _rank_share_loopback(ne, qsize, world, rank, strips, cycles=1):
     elem = dict(Dinv=geo["Dinv"][mine], metdet=geo["metdet"][mine], rmetdet=geo["rmetdet"][mine], spheremp=geo["spheremp"][mine],
                 rspheremp=geo["rspheremp"][mine], putmapP=d["putmapP"], getmapP=d["getmapP"], reverse=d["reverse"])
     os.environ["TSE_BOUNDARY_STRIPS"] = "1" if strips else "0"     # (read by tse_init)
+    os.environ.update(env or {})
     try:
-        h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), qsize, NU_Q[ne], device=0, schedule=sched)
+        h = HipMod(elem, cm.dvv(), (hv.hyai, hv.hybi, hv.ps0), qsize, NU_Q[ne], device=0, schedule=sched, lib_path=lib_path)
     finally:
-        os.environ.pop("TSE_BOUNDARY_STRIPS", None)
+        for k in ["TSE_BOUNDARY_STRIPS"] + list(env or {}):
+            os.environ.pop(k, None)
     h.comm_init(HipMod.comm_unique_id(), 0, 1)
     assert h.comm_info() == (0, 1)
     h.dcmip_init(1, geo["lat"][mine], geo["lon"][mine], hv.hyam, hv.hybm)
@@ -287,4 +289,18 @@ def test_boundary_bands_under_rccl_split_launches_leave_the_bits_of_the_regular_
     assert la != lb and lb[0] < la[0], (la, lb)                     # the bands do shrink the first launch
     for x, y, tl in zip(a, b, (1, 2)):
         assert torch.equal(x, y), "time level %d: %d values differ between the two tilings" % (tl, int((x != y).sum()))
+    assert int((a[0] != a[1]).sum()) > 0
+
+
+def test_interior_launch_on_its_own_stream_leaves_the_bits_of_the_single_stream_order():
+    """On several ranks the interior launch of every split stage runs on a stream of its own beside the boundary launch (split_stage,
+    tse_api.hip); the -DTSE_AB_HOOKS library can switch that off (TSE_AB_SPLIT_STREAMS=0: both launches on the compute stream, the
+    order up to round 4).  Pure scheduling: rank 3 of the 8-rank partition of ne120/q35 in RCCL loopback, two rsplit cycles (6 tracer
+    steps, 2 fused remaps, prefetched bounds exchanges), both ways -- the bits must not move."""
+    import torch
+    from transport_se_amd import _lib
+    a, _ = _rank_share_loopback(120, 35, 8, 3, strips=False, cycles=2, env={"TSE_AB_SPLIT_STREAMS": "1"}, lib_path=_lib.HOOKS_SO)
+    b, _ = _rank_share_loopback(120, 35, 8, 3, strips=False, cycles=2, env={"TSE_AB_SPLIT_STREAMS": "0"}, lib_path=_lib.HOOKS_SO)
+    for x, y, tl in zip(a, b, (1, 2)):
+        assert torch.equal(x, y), "time level %d: %d values differ between the two launch orders" % (tl, int((x != y).sum()))
     assert int((a[0] != a[1]).sum()) > 0
