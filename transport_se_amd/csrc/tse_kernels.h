@@ -383,7 +383,7 @@ __device__ __forceinline__ PatchId patch_slab(const GatherArgs& A) {
 
 struct GatherRaw { double2 w[2], r; };   // the lane's two own loads and its ring load
 struct RowGather {
-  unsigned own, own1;  // plane-relative byte offsets of T[.][kc][slot][pos(j*4 + (odd ? 2 : 0) + {0,1})][kk & ~1]
+  unsigned own, own1;  // plane-relative byte offsets of T[.][kc][slot][pos(j*4 + (odd ? 1 : 0) + {0,2})][kk & ~1]
   unsigned ring;       // plane-relative byte offset of the lane's half of a ring entry
   unsigned lw, lw1, lwr;  // LDS byte offsets (buffer 0) where the lane publishes its two own loads / its ring load
   unsigned lr[5];      // LDS byte offsets (buffer 0) of the lane's five neighbour values
@@ -401,12 +401,15 @@ __device__ __forceinline__ void gather_setup(RowGather& R, PatchLds<PSZ>& L, con
   const int pt[5] = {0, edge ? 0 : 3, edge ? 3 : 0, edge ? 3 : 1, edge ? 3 : 2};
   const int cn[5] = {0, edge ? 1 : 0, edge ? 0 : 2, edge ? 1 : 0, edge ? 2 : 0};
   const unsigned chunk0 = (unsigned)kc * A.S.cse;                       // first entry of the chunk
-  const int p0 = j * 4 + (odd ? 2 : 0);
+  // the two lanes of a level pair share the row's 4 points {0,2} (even level) / {1,3} (odd): the pair's first load covers points 0 and 1,
+  // its second points 2 and 3 -- where a row is a line of the slot, 64 contiguous bytes per instruction (with {0,1} / {2,3}, the form
+  // up to round 4, each instruction touched two 32-byte pieces 32 bytes apart: 0.4 ms per step, profiles/r04_ab_pair_adjacent.txt)
+  const int p0 = j * 4 + (odd ? 1 : 0), p1 = p0 + 2;
   const unsigned long long perm = A.pperm[P.slot];
   R.own = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0)) * CL + (kk & ~1)) * 8u;
-  R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p0 + 1)) * CL + (kk & ~1)) * 8u;
+  R.own1 = ((chunk0 + (unsigned)P.slot * 16 + ppos(perm, p1)) * CL + (kk & ~1)) * 8u;
   R.lw = (unsigned)(lds_own_entry(sl, p0) * CL + (kk & ~1)) * 8u;
-  R.lw1 = (unsigned)(lds_own_entry(sl, p0 + 1) * CL + (kk & ~1)) * 8u;
+  R.lw1 = (unsigned)(lds_own_entry(sl, p1) * CL + (kk & ~1)) * 8u;
   unsigned short le[5];
 #pragma unroll
   for (int m = 0; m < 5; m++) le[m] = A.plds[((size_t)P.tslot * 16 + rw[m] * 4 + pt[m]) * 3 + cn[m]];
@@ -440,7 +443,7 @@ __device__ __forceinline__ void gather_publish(const RowGather& R, PatchLds<PSZ>
   *reinterpret_cast<double2*>(base + R.lw1) = raw.w[1];
   *reinterpret_cast<double2*>(base + R.lwr) = raw.r;
   const double r0 = swz_xor4(odd ? raw.w[0].x : raw.w[0].y), r1 = swz_xor4(odd ? raw.w[1].x : raw.w[1].y);
-  v[0] = odd ? r0 : raw.w[0].x; v[1] = odd ? r1 : raw.w[1].x; v[2] = odd ? raw.w[0].y : r0; v[3] = odd ? raw.w[1].y : r1;
+  v[0] = odd ? r0 : raw.w[0].x; v[1] = odd ? raw.w[0].y : r0; v[2] = odd ? r1 : raw.w[1].x; v[3] = odd ? raw.w[1].y : r1;
   // the values must have left `raw` before the next tracer's loads are issued into it
   asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
 }
@@ -525,7 +528,7 @@ __device__ __forceinline__ void gather_var_plane(RowGather& R, PatchLds<PSZ>& L,
 }
 
 // The slab kernels' output into the scratch layout: the lane's 4 values (points i of row j at level k) leave as two 16-byte
-// stores shared with the lane that holds the other level of the pair (even level: points 0,1 for both levels; odd: 2,3),
+// stores shared with the lane that holds the other level of the pair (even level: points 0,2 for both levels; odd: 1,3),
 // instead of four 8-byte stores.  All lanes must call it (the swizzle needs both lanes of a pair); `live` gates the stores.
 struct RowStore { unsigned o0, o1; bool s0, s1; };   // plane-relative offsets (doubles) of the lane's two stores, and whether each is made
 // pexp (k_lap1<1> only): lines of the slot that hold points some other patch or rank reads (tse_api.hip: slot_perm puts every exported
@@ -533,19 +536,19 @@ struct RowStore { unsigned o0, o1; bool s0, s1; };   // plane-relative offsets (
 // from memory (k_advance<2,3> forms the Laplacian of its own slots itself), so k_lap1 writes a quarter of the field instead of all of it
 __device__ __forceinline__ RowStore row_store_setup(Scr S, const unsigned long long* __restrict__ pperm, int slot, int j, int k,
                                                     const unsigned char* __restrict__ pexp = nullptr) {
-  const int p0 = j * 4 + ((k & 1) ? 2 : 0);
+  const int p0 = j * 4 + ((k & 1) ? 1 : 0), p1 = p0 + 2;   // (points {0,2} / {1,3} of the row: as the loads, gather_setup)
   const unsigned base = (unsigned)(k / CL) * S.cse + (unsigned)slot * 16;
   const unsigned long long perm = pperm[slot];
   const int lim = pexp ? 4 * (int)pexp[slot] : 16;   // positions below `lim` are stored (whole lines)
-  return RowStore{(base + ppos(perm, p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(perm, p0 + 1)) * CL + ((k & (CL - 1)) & ~1),
-                  ppos(perm, p0) < lim, ppos(perm, p0 + 1) < lim};
+  return RowStore{(base + ppos(perm, p0)) * CL + ((k & (CL - 1)) & ~1), (base + ppos(perm, p1)) * CL + ((k & (CL - 1)) & ~1),
+                  ppos(perm, p0) < lim, ppos(perm, p1) < lim};
 }
 __device__ __forceinline__ void store_row_pair(double* __restrict__ plane /* &T[q][0] */, const RowStore& R, int k, bool live, const double v[4]) {
   const bool odd = k & 1;
-  const double r0 = swz_xor4(odd ? v[0] : v[2]), r1 = swz_xor4(odd ? v[1] : v[3]);
+  const double r0 = swz_xor4(odd ? v[0] : v[1]), r1 = swz_xor4(odd ? v[2] : v[3]);
   if (live) {
-    if (R.s0) *reinterpret_cast<double2*>(plane + R.o0) = odd ? make_double2(r0, v[2]) : make_double2(v[0], r0);
-    if (R.s1) *reinterpret_cast<double2*>(plane + R.o1) = odd ? make_double2(r1, v[3]) : make_double2(v[1], r1);
+    if (R.s0) *reinterpret_cast<double2*>(plane + R.o0) = odd ? make_double2(r0, v[1]) : make_double2(v[0], r0);
+    if (R.s1) *reinterpret_cast<double2*>(plane + R.o1) = odd ? make_double2(r1, v[3]) : make_double2(v[2], r1);
   }
 }
 // received halo -> the halo columns of every tracer plane of a scratch field (only before a DSS-on-read consumer)
